@@ -1,0 +1,75 @@
+// kernels.h -- launch wrappers of the gfx950 kernels (kernels.hip), used by lstm_hip_api.cpp.
+// Every wrapper enqueues on `st` and returns; no host synchronisation, no allocation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lstmk {
+
+// flat parameter block offsets [W | U | b | Why | by], floats
+struct ParamLayout {
+    size_t W, U, b, Why, by, total;
+    __host__ __device__ static ParamLayout make(int N, int M) {
+        ParamLayout p;
+        p.W = 0;
+        p.U = p.W + (size_t)4 * N * M;
+        p.b = p.U + (size_t)4 * N * N;
+        p.Why = p.b + (size_t)4 * N;
+        p.by = p.Why + (size_t)M * N;
+        p.total = p.by + (size_t)M;
+        return p;
+    }
+};
+
+// ---- recurrent weight repack (once per window, after Adagrad) -------------------------------
+// Ufwd[N/4][N/16][64] float4 : MFMA 16x16x4 A-fragments of U for the forward product
+// Ubwd[N/16][N/4][64] float4 : A-fragments of U^T for the backward product
+void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st);
+
+// ---- baseline engine: one launch per timestep -----------------------------------------------
+// g = U*h_prev + W[:,x] + b ; gates ; c = tanh(i*u + f*c_prev) ; h = o*c      (R/lstm.cc:176-192)
+void fwd_step(const float4 *Ufwd, const float *W, const float *bias, const float *Hprev, const float *Cprev,
+              float *Hout, float *Cout, float *Gout, const int32_t *xi_t, int N, int B, bool fast, hipStream_t st);
+// dh = DHy[t] + U^T*dg[t+1] ; dc ; dg[t] ; dcnext                              (R/lstm.cc:228-256)
+void bwd_step(const float4 *Ubwd, const float *DGnext /*null at t=S-1*/, const float *DHy_t, const float *G_t,
+              const float *C_t, const float *Cprev, float *dcnext, float *DG_t, int N, int B, hipStream_t st);
+
+// ---- time-batched dense products (fp32 MFMA 32x32x2, LDS tiled) ------------------------------
+// C[M x Nn] = op(A)[M x K] * op(B)[K x Nn], column-major; TA: A is stored K x M; TB: B is stored Nn x K.
+// splits > 1 writes `splits` partial slabs into `slabs` (each M*Nn floats, ld = M); gemm_reduce
+// sums them into C in slab order (deterministic).  `slabs` must hold splits*M*Nn floats.
+void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+          int splits, float *slabs, hipStream_t st);
+int gemm_pick_splits(int M, int Nn, int K);
+
+// ---- output layer elementwise: probs = exp(y+by)/sum ; loss ; dy = probs - onehot  (R/lstm.cc:195-207,225)
+// Y is [T cols][256] (column-major 256 x T) and is overwritten by dY; probs written to P.
+// colloss[col] = -log2 p[target] (0 for an empty target); dby_part[wave][256] partial row sums of dY.
+void softmax_loss_dy(float *Y, float *P, const float *by, const int32_t *ti, float *colloss, float *dby_part, int T,
+                     int *n_parts_out, hipStream_t st);
+void dby_finish(const float *dby_part, int n_parts, float *dby, hipStream_t st);
+// window loss as the reference sums it: for each t a float sum over b, / B_global, accumulated in double
+void loss_reduce(const float *colloss, int steps, int B, int B_global, double *out, hipStream_t st);
+
+// ---- dW = DG * X^T and db = rowsum(DG)                                        (R/lstm.cc:251-252)
+// X is one-hot, so dW[:,v] is the sum of the DG columns whose input byte is v: each workgroup owns
+// DW_ROWS gate rows, streams over the T columns and accumulates into a [257][rows][copies] LDS
+// table with ds_add_f32 (bucket 256 = empty input column).  Every LDS word is touched by ONE thread
+// in column order, so the result is deterministic.  db[r] = sum over the 257 buckets.
+void dW_db(const float *DG /*[T][G4]*/, const int32_t *xi /*[T]*/, int T, int G4, float *dW /*[256][G4]*/, float *db,
+           hipStream_t st);
+
+// ---- Adagrad over the flat block (R/lstm.cc:261-272; eps added in double, :25,46-48)
+void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, hipStream_t st);
+
+// ---- window builder on the device (OV/lstm_eigen_opt/lstm.cc:190-213), one thread per stream
+void slide_window(const uint8_t *text, uint64_t len, uint64_t *pos, int32_t *xi, int32_t *ti, int S, int B,
+                  hipStream_t st);
+
+// ---- B = 1 recurrence for the evaluator / sampler (OV/lstm_eigen_class_CUDA/lstm.cc:578-720)
+void eval_bits(const float *P, int N, const uint8_t *text, uint64_t len, double *out_bits_sum, float *scratch,
+               hipStream_t st);
+void sample(const float *P, int N, float *hc /*2N*/, const double *u, int count, uint8_t *out, float *scratch,
+            hipStream_t st);
+
+} // namespace lstmk

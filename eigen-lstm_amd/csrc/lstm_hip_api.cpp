@@ -1,0 +1,588 @@
+// lstm_hip_api.cpp -- the C ABI of include/lstm_hip.h over the gfx950 kernels.
+//
+// One lstm_hip_ctx = what the reference keeps in cuParameters p, d, m and cuLSTM<S>
+// (OV/lstm_eigen_class_CUDA/cu_lstm.h:20-304), laid out for one MI355X:
+//   P, dP, mem : flat [W|U|b|Why|by] blocks (dP is also the RCCL all-reduce payload)
+//   H, C       : [S][B][N]   (= N x (S*B) column-major; columns t*B.. are step t)
+//   G, DG      : [S][B][4N]  post-activation gates / their gradients
+//   Y          : [S][B][256] logits, overwritten in place by dY;  Pr: probs
+//   DHy        : [S][B][N]   Why^T * dY for every step at once
+// so the time-batched products see plain column-major matrices with T = (S-1)*B columns.
+#include "../../include/lstm_hip.h"
+#include "kernels.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace lstmk;
+
+namespace {
+
+thread_local char g_err[512] = "";
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(LSTM_HIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+enum KernelId {
+    K_PACK_U, K_FWD_STEP, K_GEMM_Y, K_SOFTMAX, K_LOSS, K_GEMM_DHY, K_BWD_STEP, K_GEMM_DWHY, K_GEMM_DU, K_DW_DB,
+    K_DBY, K_ADAGRAD, K_SLIDE, K_ALLREDUCE, K_COUNT
+};
+const char *const kKernelNames[K_COUNT] = {
+    "pack_U", "fwd_step", "gemm_Y", "softmax_loss_dy", "loss_reduce", "gemm_DHy", "bwd_step", "gemm_dWhy", "gemm_dU",
+    "dW_db", "dby_finish", "adagrad", "slide", "allreduce"};
+
+// ---- RCCL, loaded on first use so single-GPU users never touch it --------------------------
+struct UniqueId {
+    char internal[LSTM_HIP_UNIQUE_ID_BYTES];
+};
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+int rccl_load() {
+    if (g_rccl.lib) return 0;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(LSTM_HIP_ERCCL, "cannot load librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(LSTM_HIP_ERCCL, "librccl lacks a required symbol");
+    g_rccl.lib = lib;
+    return 0;
+}
+
+} // namespace
+
+struct lstm_hip_ctx {
+    lstm_hip_config cfg{};
+    ParamLayout pl{};
+    int T = 0; // (S-1)*B columns in the time-batched matrices
+    hipStream_t st = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    float *P = nullptr, *dP = nullptr, *mem = nullptr;
+    float4 *Ufwd = nullptr, *Ubwd = nullptr;
+    bool packed = false;
+    float *H = nullptr, *C = nullptr, *G = nullptr, *DG = nullptr, *Y = nullptr, *Pr = nullptr, *DHy = nullptr;
+    float *dcnext = nullptr, *colloss = nullptr, *dby_part = nullptr, *slabs = nullptr;
+    int n_dby_parts = 0;
+    int splits_dWhy = 1, splits_dU = 1;
+    int32_t *xi = nullptr, *ti = nullptr;
+    double *d_loss = nullptr;
+    double *d_losses = nullptr;
+    int64_t losses_cap = 0;
+    uint8_t *text = nullptr;
+    uint64_t text_len = 0;
+    uint64_t *pos = nullptr;
+    int32_t global_B = 0;
+    bool fwd_done = false;
+
+    void *comm = nullptr;
+    int nranks = 1, rank = 0;
+
+    bool profiling = false;
+    int64_t launches[K_COUNT] = {};
+    double total_ms[K_COUNT] = {};
+};
+
+namespace {
+
+template <class F> int timed(lstm_hip_ctx *h, int id, F &&launch) {
+    if (!h->profiling) {
+        launch();
+        return 0;
+    }
+    HIP_TRY(hipEventRecord(h->ev0, h->st));
+    launch();
+    HIP_TRY(hipEventRecord(h->ev1, h->st));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->launches[id]++;
+    h->total_ms[id] += ms;
+    return 0;
+}
+#define RUN(id, ...)                                               \
+    do {                                                           \
+        int rc_ = timed(h, id, [&]() { __VA_ARGS__; });            \
+        if (rc_) return rc_;                                       \
+    } while (0)
+
+template <class T> int dalloc(T **p, size_t count) {
+    HIP_TRY(hipMalloc((void **)p, count * sizeof(T)));
+    HIP_TRY(hipMemset(*p, 0, count * sizeof(T)));
+    return 0;
+}
+#define ALLOC(p, n)                  \
+    do {                             \
+        int rc_ = dalloc(&(p), (n)); \
+        if (rc_) return rc_;         \
+    } while (0)
+
+int check(lstm_hip_ctx *h) {
+    if (!h) return fail(LSTM_HIP_EINVAL, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    return 0;
+}
+#define CHECK(h)             \
+    do {                     \
+        int rc_ = check(h);  \
+        if (rc_) return rc_; \
+    } while (0)
+
+int do_forward(lstm_hip_ctx *h) {
+    const int N = h->cfg.N, B = h->cfg.B, S = h->cfg.S, G4 = 4 * N;
+    const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
+    if (!h->packed) {
+        RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd, h->Ubwd, N, h->st));
+        h->packed = true;
+    }
+    for (int t = 1; t < S; t++) {
+        RUN(K_FWD_STEP, fwd_step(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H + (size_t)(t - 1) * N * B,
+                                 h->C + (size_t)(t - 1) * N * B, h->H + (size_t)t * N * B, h->C + (size_t)t * N * B,
+                                 h->G + (size_t)t * G4 * B, h->xi + (size_t)t * B, N, B, fast, h->st));
+    }
+    // Y = Why * H[1..S-1]   (R/lstm.cc:195 for every step at once)
+    RUN(K_GEMM_Y, gemm(false, false, 256, h->T, N, h->P + h->pl.Why, 256, h->H + (size_t)N * B, N,
+                       h->Y + (size_t)256 * B, 256, 1, nullptr, h->st));
+    RUN(K_SOFTMAX, softmax_loss_dy(h->Y + (size_t)256 * B, h->Pr + (size_t)256 * B, h->P + h->pl.by, h->ti + B,
+                                   h->colloss, h->dby_part, h->T, &h->n_dby_parts, h->st));
+    h->fwd_done = true;
+    return 0;
+}
+
+int do_backward(lstm_hip_ctx *h) {
+    const int N = h->cfg.N, B = h->cfg.B, S = h->cfg.S, G4 = 4 * N, T = h->T;
+    if (!h->fwd_done) return fail(LSTM_HIP_ESTATE, "backward called before forward");
+    float *dY = h->Y + (size_t)256 * B;
+    // dby = rowsum(dY)                 R/lstm.cc:227
+    RUN(K_DBY, dby_finish(h->dby_part, h->n_dby_parts, h->dP + h->pl.by, h->st));
+    // DHy = Why^T * dY                 R/lstm.cc:228, all steps
+    RUN(K_GEMM_DHY, gemm(true, false, N, T, 256, h->P + h->pl.Why, 256, dY, 256, h->DHy + (size_t)N * B, N, 1, nullptr,
+                         h->st));
+    HIP_TRY(hipMemsetAsync(h->dcnext, 0, sizeof(float) * N * B, h->st)); // R/lstm.cc:216-217
+    for (int t = S - 1; t >= 1; t--) {
+        RUN(K_BWD_STEP, bwd_step(h->Ubwd, t < S - 1 ? h->DG + (size_t)(t + 1) * G4 * B : nullptr,
+                                 h->DHy + (size_t)t * N * B, h->G + (size_t)t * G4 * B, h->C + (size_t)t * N * B,
+                                 h->C + (size_t)(t - 1) * N * B, h->dcnext, h->DG + (size_t)t * G4 * B, N, B, h->st));
+    }
+    // dWhy = dY * H[1..]^T             R/lstm.cc:226
+    RUN(K_GEMM_DWHY, gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256,
+                          h->splits_dWhy, h->slabs, h->st));
+    // dU = DG * H[0..S-2]^T            R/lstm.cc:250
+    RUN(K_GEMM_DU, gemm(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->dP + h->pl.U, G4, h->splits_dU,
+                        h->slabs, h->st));
+    // dW, db                           R/lstm.cc:251-252
+    RUN(K_DW_DB, dW_db(h->DG + (size_t)G4 * B, h->xi + B, T, G4, h->dP + h->pl.W, h->dP + h->pl.b, h->st));
+    return 0;
+}
+
+int do_allreduce(lstm_hip_ctx *h) {
+    if (!h->comm) return 0;
+    int rc = 0;
+    RUN(K_ALLREDUCE, rc = g_rccl.AllReduce(h->dP, h->dP, h->pl.total, /*ncclFloat*/ 7, /*ncclSum*/ 0, h->comm, h->st));
+    if (rc != 0)
+        return fail(LSTM_HIP_ERCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    return 0;
+}
+
+int do_adagrad(lstm_hip_ctx *h, double lr) {
+    RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->st));
+    h->packed = false;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *lstm_hip_last_error(void) { return g_err; }
+
+size_t lstm_hip_param_count(int32_t N, int32_t M) { return ParamLayout::make(N, M).total; }
+
+int lstm_hip_device_info(int32_t device, char name[64], int32_t *cus, int32_t *clock_mhz) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (name) snprintf(name, 64, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cus) *cus = prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
+    return 0;
+}
+
+int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
+    if (!cfg || !out) return fail(LSTM_HIP_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->M != LSTM_HIP_VOCAB) return fail(LSTM_HIP_EINVAL, "M must be %d (got %d)", LSTM_HIP_VOCAB, cfg->M);
+    if (cfg->N < 16 || cfg->N % 16 != 0) return fail(LSTM_HIP_EINVAL, "N must be a positive multiple of 16 (got %d)", cfg->N);
+    if (cfg->S < 2) return fail(LSTM_HIP_EINVAL, "S must be >= 2 (got %d)", cfg->S);
+    if (cfg->B < 1) return fail(LSTM_HIP_EINVAL, "B must be >= 1 (got %d)", cfg->B);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LSTM_HIP_ENODEV, "no HIP device visible");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(LSTM_HIP_ENODEV, "device %d out of range (%d visible)", cfg->device, ndev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(LSTM_HIP_ENODEV, "device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    lstm_hip_ctx *h = new lstm_hip_ctx();
+    h->cfg = *cfg;
+    h->pl = ParamLayout::make(cfg->N, cfg->M);
+    const size_t N = cfg->N, B = cfg->B, S = cfg->S, G4 = 4 * N;
+    h->T = (int)((S - 1) * B);
+    h->global_B = cfg->B;
+    HIP_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+    ALLOC(h->P, h->pl.total);
+    ALLOC(h->dP, h->pl.total);
+    ALLOC(h->mem, h->pl.total);
+    ALLOC(h->Ufwd, N * N);
+    ALLOC(h->Ubwd, N * N);
+    ALLOC(h->H, N * B * S);
+    ALLOC(h->C, N * B * S);
+    ALLOC(h->G, G4 * B * S);
+    ALLOC(h->DG, G4 * B * S);
+    ALLOC(h->Y, 256 * B * S);
+    ALLOC(h->Pr, 256 * B * S);
+    ALLOC(h->DHy, N * B * S);
+    ALLOC(h->dcnext, N * B);
+    ALLOC(h->colloss, B * S);
+    ALLOC(h->dby_part, (size_t)256 * (h->T / 8 + 8));
+    h->splits_dWhy = gemm_pick_splits(256, (int)N, h->T);
+    h->splits_dU = gemm_pick_splits((int)G4, (int)N, h->T);
+    {
+        size_t a = (size_t)h->splits_dWhy * 256 * N, b = (size_t)h->splits_dU * G4 * N;
+        ALLOC(h->slabs, a > b ? a : b);
+    }
+    ALLOC(h->xi, S * B);
+    ALLOC(h->ti, S * B);
+    HIP_TRY(hipMemset(h->xi, 0xff, sizeof(int32_t) * S * B)); // -1: all-zero columns (opt:122,125)
+    HIP_TRY(hipMemset(h->ti, 0xff, sizeof(int32_t) * S * B));
+    ALLOC(h->d_loss, 1);
+    ALLOC(h->pos, B);
+    HIP_TRY(hipDeviceSynchronize());
+    *out = h;
+    return 0;
+}
+
+int lstm_hip_destroy(lstm_hip_t *h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipStreamSynchronize(h->st);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
+                    h->colloss, h->dby_part, h->slabs, h->xi, h->ti, h->d_loss, h->d_losses, h->text, h->pos};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->st) (void)hipStreamDestroy(h->st);
+    delete h;
+    return 0;
+}
+
+static float *block_of(lstm_hip_ctx *h, int which) { return which == 0 ? h->P : which == 1 ? h->dP : which == 2 ? h->mem : nullptr; }
+
+int lstm_hip_set_params(lstm_hip_t *h, int which, const float *host_block) {
+    CHECK(h);
+    float *dst = block_of(h, which);
+    if (!dst || !host_block) return fail(LSTM_HIP_EINVAL, "set_params: bad block id %d or null pointer", which);
+    HIP_TRY(hipMemcpyAsync(dst, host_block, sizeof(float) * h->pl.total, hipMemcpyHostToDevice, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    if (which == 0) h->packed = false;
+    return 0;
+}
+int lstm_hip_get_params(lstm_hip_t *h, int which, float *host_block) {
+    CHECK(h);
+    float *src = block_of(h, which);
+    if (!src || !host_block) return fail(LSTM_HIP_EINVAL, "get_params: bad block id %d or null pointer", which);
+    HIP_TRY(hipMemcpyAsync(host_block, src, sizeof(float) * h->pl.total, hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int lstm_hip_set_state(lstm_hip_t *h, int32_t t, const float *h_t, const float *c_t) {
+    CHECK(h);
+    if (t < 0 || t >= h->cfg.S) return fail(LSTM_HIP_EINVAL, "set_state: t=%d outside [0,%d)", t, h->cfg.S);
+    const size_t n = (size_t)h->cfg.N * h->cfg.B;
+    if (h_t) HIP_TRY(hipMemcpyAsync(h->H + t * n, h_t, sizeof(float) * n, hipMemcpyHostToDevice, h->st));
+    if (c_t) HIP_TRY(hipMemcpyAsync(h->C + t * n, c_t, sizeof(float) * n, hipMemcpyHostToDevice, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    return 0;
+}
+int lstm_hip_get_state(lstm_hip_t *h, int32_t t, float *h_t, float *c_t) {
+    CHECK(h);
+    if (t < 0 || t >= h->cfg.S) return fail(LSTM_HIP_EINVAL, "get_state: t=%d outside [0,%d)", t, h->cfg.S);
+    const size_t n = (size_t)h->cfg.N * h->cfg.B;
+    if (h_t) HIP_TRY(hipMemcpyAsync(h_t, h->H + t * n, sizeof(float) * n, hipMemcpyDeviceToHost, h->st));
+    if (c_t) HIP_TRY(hipMemcpyAsync(c_t, h->C + t * n, sizeof(float) * n, hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    return 0;
+}
+int lstm_hip_get_activations(lstm_hip_t *h, int32_t t, float *g_t, float *probs_t) {
+    CHECK(h);
+    if (t < 1 || t >= h->cfg.S) return fail(LSTM_HIP_EINVAL, "get_activations: t=%d outside [1,%d)", t, h->cfg.S);
+    const size_t B = h->cfg.B, G4 = 4 * (size_t)h->cfg.N;
+    if (g_t) HIP_TRY(hipMemcpyAsync(g_t, h->G + t * G4 * B, sizeof(float) * G4 * B, hipMemcpyDeviceToHost, h->st));
+    if (probs_t) HIP_TRY(hipMemcpyAsync(probs_t, h->Pr + t * 256 * B, sizeof(float) * 256 * B, hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int lstm_hip_set_window(lstm_hip_t *h, const int32_t *xi, const int32_t *ti) {
+    CHECK(h);
+    if (!xi || !ti) return fail(LSTM_HIP_EINVAL, "set_window: null pointer");
+    const size_t n = (size_t)h->cfg.S * h->cfg.B;
+    for (size_t i = 0; i < n; i++)
+        if (xi[i] >= LSTM_HIP_VOCAB || ti[i] >= LSTM_HIP_VOCAB)
+            return fail(LSTM_HIP_EINVAL, "set_window: index %d/%d at %zu is >= %d", xi[i], ti[i], i, LSTM_HIP_VOCAB);
+    HIP_TRY(hipMemcpyAsync(h->xi, xi, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->st));
+    HIP_TRY(hipMemcpyAsync(h->ti, ti, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    return 0;
+}
+int lstm_hip_get_window(lstm_hip_t *h, int32_t *xi, int32_t *ti) {
+    CHECK(h);
+    const size_t n = (size_t)h->cfg.S * h->cfg.B;
+    if (xi) HIP_TRY(hipMemcpyAsync(xi, h->xi, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->st));
+    if (ti) HIP_TRY(hipMemcpyAsync(ti, h->ti, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    return 0;
+}
+int lstm_hip_reset_window(lstm_hip_t *h) {
+    CHECK(h);
+    const size_t n = (size_t)h->cfg.S * h->cfg.B;
+    HIP_TRY(hipMemsetAsync(h->xi, 0xff, sizeof(int32_t) * n, h->st));
+    HIP_TRY(hipMemsetAsync(h->ti, 0xff, sizeof(int32_t) * n, h->st));
+    return 0;
+}
+
+static int slide_state(lstm_hip_ctx *h) {
+    const size_t n = (size_t)h->cfg.N * h->cfg.B;
+    if (h->cfg.S < 2) return 0;
+    HIP_TRY(hipMemcpyAsync(h->H, h->H + n, sizeof(float) * n, hipMemcpyDeviceToDevice, h->st));
+    HIP_TRY(hipMemcpyAsync(h->C, h->C + n, sizeof(float) * n, hipMemcpyDeviceToDevice, h->st));
+    return 0;
+}
+int lstm_hip_slide_state(lstm_hip_t *h) {
+    CHECK(h);
+    return slide_state(h);
+}
+
+int lstm_hip_forward(lstm_hip_t *h) {
+    CHECK(h);
+    return do_forward(h);
+}
+int lstm_hip_loss(lstm_hip_t *h, double *loss_bits) {
+    CHECK(h);
+    if (!loss_bits) return fail(LSTM_HIP_EINVAL, "loss: null pointer");
+    if (!h->fwd_done) return fail(LSTM_HIP_ESTATE, "loss called before forward");
+    RUN(K_LOSS, loss_reduce(h->colloss, h->cfg.S - 1, h->cfg.B, h->global_B, h->d_loss, h->st));
+    HIP_TRY(hipMemcpyAsync(loss_bits, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    return 0;
+}
+int lstm_hip_backward(lstm_hip_t *h) {
+    CHECK(h);
+    return do_backward(h);
+}
+int lstm_hip_adagrad(lstm_hip_t *h, double learning_rate) {
+    CHECK(h);
+    return do_adagrad(h, learning_rate);
+}
+
+int lstm_hip_comm_unique_id(uint8_t id[LSTM_HIP_UNIQUE_ID_BYTES]) {
+    int rc = rccl_load();
+    if (rc) return rc;
+    UniqueId u;
+    rc = g_rccl.GetUniqueId(&u);
+    if (rc != 0) return fail(LSTM_HIP_ERCCL, "ncclGetUniqueId failed (%d)", rc);
+    memcpy(id, u.internal, LSTM_HIP_UNIQUE_ID_BYTES);
+    return 0;
+}
+int lstm_hip_comm_init(lstm_hip_t *h, const uint8_t id[LSTM_HIP_UNIQUE_ID_BYTES], int32_t nranks, int32_t rank) {
+    CHECK(h);
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(LSTM_HIP_EINVAL, "comm_init: rank %d of %d", rank, nranks);
+    int rc = rccl_load();
+    if (rc) return rc;
+    UniqueId u;
+    memcpy(u.internal, id, LSTM_HIP_UNIQUE_ID_BYTES);
+    rc = g_rccl.CommInitRank(&h->comm, nranks, u, rank);
+    if (rc != 0) {
+        h->comm = nullptr;
+        return fail(LSTM_HIP_ERCCL, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    }
+    h->nranks = nranks;
+    h->rank = rank;
+    return 0;
+}
+int lstm_hip_allreduce_grads(lstm_hip_t *h) {
+    CHECK(h);
+    return do_allreduce(h);
+}
+
+int lstm_hip_set_text(lstm_hip_t *h, const uint8_t *text, size_t len) {
+    CHECK(h);
+    if (!text || len <= (size_t)h->cfg.S) return fail(LSTM_HIP_EINVAL, "set_text: need more than S=%d bytes (got %zu)", h->cfg.S, len);
+    HIP_TRY(hipStreamSynchronize(h->st));
+    if (h->text) HIP_TRY(hipFree(h->text));
+    h->text = nullptr;
+    HIP_TRY(hipMalloc((void **)&h->text, len));
+    HIP_TRY(hipMemcpy(h->text, text, len, hipMemcpyHostToDevice));
+    h->text_len = len;
+    return 0;
+}
+int lstm_hip_set_cursors(lstm_hip_t *h, const uint64_t *pos) {
+    CHECK(h);
+    if (!pos) return fail(LSTM_HIP_EINVAL, "set_cursors: null pointer");
+    if (!h->text) return fail(LSTM_HIP_ESTATE, "set_cursors before set_text");
+    for (int b = 0; b < h->cfg.B; b++)
+        if (pos[b] >= h->text_len) return fail(LSTM_HIP_EINVAL, "set_cursors: pos[%d]=%llu >= len %llu", b, (unsigned long long)pos[b], (unsigned long long)h->text_len);
+    HIP_TRY(hipMemcpyAsync(h->pos, pos, sizeof(uint64_t) * h->cfg.B, hipMemcpyHostToDevice, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    return 0;
+}
+int lstm_hip_get_cursors(lstm_hip_t *h, uint64_t *pos) {
+    CHECK(h);
+    if (!pos) return fail(LSTM_HIP_EINVAL, "get_cursors: null pointer");
+    HIP_TRY(hipMemcpyAsync(pos, h->pos, sizeof(uint64_t) * h->cfg.B, hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    return 0;
+}
+int lstm_hip_set_global_batch(lstm_hip_t *h, int32_t global_B) {
+    if (!h || global_B < h->cfg.B) return fail(LSTM_HIP_EINVAL, "set_global_batch: %d < local B", global_B);
+    h->global_B = global_B;
+    return 0;
+}
+
+int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, double *losses, float *elapsed_ms) {
+    CHECK(h);
+    if (count < 0) return fail(LSTM_HIP_EINVAL, "train_windows: count < 0");
+    if (!h->text) return fail(LSTM_HIP_ESTATE, "train_windows before set_text/set_cursors");
+    if (count > h->losses_cap) {
+        HIP_TRY(hipStreamSynchronize(h->st));
+        if (h->d_losses) HIP_TRY(hipFree(h->d_losses));
+        h->d_losses = nullptr;
+        HIP_TRY(hipMalloc((void **)&h->d_losses, sizeof(double) * count));
+        h->losses_cap = count;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (elapsed_ms) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, h->st));
+    }
+    for (int64_t i = 0; i < count; i++) {
+        RUN(K_SLIDE, slide_window(h->text, h->text_len, h->pos, h->xi, h->ti, h->cfg.S, h->cfg.B, h->st));
+        int rc = slide_state(h);
+        if (rc) return rc;
+        if ((rc = do_forward(h))) return rc;
+        RUN(K_LOSS, loss_reduce(h->colloss, h->cfg.S - 1, h->cfg.B, h->global_B, h->d_losses + i, h->st));
+        if ((rc = do_backward(h))) return rc;
+        if ((rc = do_allreduce(h))) return rc;
+        if ((rc = do_adagrad(h, learning_rate))) return rc;
+    }
+    if (elapsed_ms) {
+        HIP_TRY(hipEventRecord(e1, h->st));
+        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(elapsed_ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    if (losses && count > 0)
+        HIP_TRY(hipMemcpyAsync(losses, h->d_losses, sizeof(double) * count, hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int lstm_hip_eval_bits(lstm_hip_t *h, const uint8_t *text, size_t len, double *bits_per_char) {
+    CHECK(h);
+    if (!text || len < 2 || !bits_per_char) return fail(LSTM_HIP_EINVAL, "eval_bits: need >= 2 bytes and an output pointer");
+    uint8_t *d_text = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_text, len));
+    HIP_TRY(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, h->st));
+    eval_bits(h->P, h->cfg.N, d_text, len, h->d_loss, nullptr, h->st);
+    double sum = 0.0;
+    HIP_TRY(hipMemcpyAsync(&sum, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    HIP_TRY(hipFree(d_text));
+    *bits_per_char = sum / (double)(len - 1);
+    return 0;
+}
+
+int lstm_hip_sample(lstm_hip_t *h, float *h0, float *c0, const double *u, int32_t count, uint8_t *out) {
+    CHECK(h);
+    if (!h0 || !c0 || !u || !out || count < 0) return fail(LSTM_HIP_EINVAL, "sample: null pointer or negative count");
+    const int N = h->cfg.N;
+    float *d_hc = nullptr;
+    double *d_u = nullptr;
+    uint8_t *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_hc, sizeof(float) * 2 * N));
+    HIP_TRY(hipMalloc((void **)&d_u, sizeof(double) * (count + 1)));
+    HIP_TRY(hipMalloc((void **)&d_out, (size_t)count + 1));
+    HIP_TRY(hipMemcpyAsync(d_hc, h0, sizeof(float) * N, hipMemcpyHostToDevice, h->st));
+    HIP_TRY(hipMemcpyAsync(d_hc + N, c0, sizeof(float) * N, hipMemcpyHostToDevice, h->st));
+    HIP_TRY(hipMemcpyAsync(d_u, u, sizeof(double) * count, hipMemcpyHostToDevice, h->st));
+    sample(h->P, N, d_hc, d_u, count, d_out, nullptr, h->st);
+    HIP_TRY(hipMemcpyAsync(h0, d_hc, sizeof(float) * N, hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipMemcpyAsync(c0, d_hc + N, sizeof(float) * N, hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipMemcpyAsync(out, d_out, count, hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    (void)hipFree(d_hc);
+    (void)hipFree(d_u);
+    (void)hipFree(d_out);
+    return 0;
+}
+
+int lstm_hip_synchronize(lstm_hip_t *h) {
+    CHECK(h);
+    HIP_TRY(hipStreamSynchronize(h->st));
+    return 0;
+}
+int lstm_hip_set_profiling(lstm_hip_t *h, int32_t on) {
+    if (!h) return fail(LSTM_HIP_EINVAL, "null handle");
+    h->profiling = on != 0;
+    return 0;
+}
+int lstm_hip_kernel_stat_count(lstm_hip_t *) { return K_COUNT; }
+int lstm_hip_kernel_stat(lstm_hip_t *h, int32_t idx, const char **name, int64_t *launches, double *total_ms) {
+    if (!h || idx < 0 || idx >= K_COUNT) return fail(LSTM_HIP_EINVAL, "kernel_stat: bad index %d", idx);
+    if (name) *name = kKernelNames[idx];
+    if (launches) *launches = h->launches[idx];
+    if (total_ms) *total_ms = h->total_ms[idx];
+    return 0;
+}
+int lstm_hip_reset_kernel_stats(lstm_hip_t *h) {
+    if (!h) return fail(LSTM_HIP_EINVAL, "null handle");
+    memset(h->launches, 0, sizeof(h->launches));
+    memset(h->total_ms, 0, sizeof(h->total_ms));
+    return 0;
+}
+
+} // extern "C"

@@ -202,12 +202,18 @@ void FN(ref_forward)(int N, int M, int S, int B, const REAL *P, const int32_t *x
         for (int b = 0; b < B; b++) {
             REAL *gc = gt + (size_t)b * G;
             /* g = W*x + U*h_prev + b   (opt:219) */
+            /* loops run k-outer / r-inner for cache locality; each gc[r] still accumulates its
+             * products in ascending k, so the rounding sequence is that of a plain dot product */
             int xk = xi[t * B + b];
+            for (int r = 0; r < G; r++) gc[r] = 0;
+            for (int k = 0; k < N; k++) {
+                const REAL hk = hp[(size_t)b * N + k];
+                const REAL *Uk = p.U + (size_t)k * G;
+                for (int r = 0; r < G; r++) gc[r] += Uk[r] * hk;
+            }
             for (int r = 0; r < G; r++) {
                 REAL acc = xk >= 0 ? p.W[(size_t)xk * G + r] : (REAL)0;
-                REAL uh = 0;
-                for (int k = 0; k < N; k++) uh += p.U[(size_t)k * G + r] * hp[(size_t)b * N + k];
-                gc[r] = (acc + uh) + p.b[r];
+                gc[r] = (acc + gc[r]) + p.b[r];
             }
             /* sigmoid on i,o,f; tanh on u   (opt:222-224) */
             for (int r = 0; r < 3 * N; r++) gc[r] = logistic(gc[r]);
@@ -221,11 +227,14 @@ void FN(ref_forward)(int N, int M, int S, int B, const REAL *P, const int32_t *x
             /* y = Why*h + by; probs = exp(y)/sum   (opt:236-242), no max shift */
             REAL *pc = pt + (size_t)b * M;
             REAL sum = 0;
+            for (int m = 0; m < M; m++) pc[m] = 0;
+            for (int k = 0; k < N; k++) {
+                const REAL hk = ht[(size_t)b * N + k];
+                const REAL *Wk = p.Why + (size_t)k * M;
+                for (int m = 0; m < M; m++) pc[m] += Wk[m] * hk;
+            }
             for (int m = 0; m < M; m++) {
-                REAL y = 0;
-                for (int k = 0; k < N; k++) y += p.Why[(size_t)k * M + m] * ht[(size_t)b * N + k];
-                y += p.by[m];
-                pc[m] = EXP(y);
+                pc[m] = EXP(pc[m] + p.by[m]);
                 sum += pc[m];
             }
             for (int m = 0; m < M; m++) pc[m] = pc[m] / sum;
@@ -260,6 +269,7 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
     REAL *dg = (REAL *)malloc(sizeof(REAL) * G * B);
     REAL *dhnext = (REAL *)calloc((size_t)N * B, sizeof(REAL));
     REAL *dcnext = (REAL *)calloc((size_t)N * B, sizeof(REAL));
+    REAL *utmp = (REAL *)malloc(sizeof(REAL) * (size_t)N * G);
     for (int t = S - 1; t > 0; t--) {
         const REAL *gt = g + (size_t)t * G * B, *ht = h + (size_t)t * N * B, *ct = c + (size_t)t * N * B;
         const REAL *hp = h + (size_t)(t - 1) * N * B, *cp = c + (size_t)(t - 1) * N * B;
@@ -271,12 +281,15 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
         }
         /* dWhy += dy * h^T ; dby += rowsum(dy)   (opt:271-272) */
 #pragma omp parallel for schedule(static)
-        for (int k = 0; k < N; k++)
-            for (int m = 0; m < M; m++) {
-                REAL acc = 0;
-                for (int b = 0; b < B; b++) acc += dy[(size_t)b * M + m] * ht[(size_t)b * N + k];
-                d.Why[(size_t)k * M + m] += acc;
+        for (int k = 0; k < N; k++) {
+            REAL tmp[256];
+            for (int m = 0; m < M; m++) tmp[m] = 0;
+            for (int b = 0; b < B; b++) {
+                const REAL hk = ht[(size_t)b * N + k];
+                for (int m = 0; m < M; m++) tmp[m] += dy[(size_t)b * M + m] * hk;
             }
+            for (int m = 0; m < M; m++) d.Why[(size_t)k * M + m] += tmp[m];
+        }
         for (int m = 0; m < M; m++) {
             REAL acc = 0;
             for (int b = 0; b < B; b++) acc += dy[(size_t)b * M + m];
@@ -308,12 +321,16 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
         }
         /* dU += dg * h_prev^T ; dW += dg * x^T ; db += rowsum(dg)   (opt:297-299) */
 #pragma omp parallel for schedule(static)
-        for (int k = 0; k < N; k++)
-            for (int r = 0; r < G; r++) {
-                REAL acc = 0;
-                for (int b = 0; b < B; b++) acc += dg[(size_t)b * G + r] * hp[(size_t)b * N + k];
-                d.U[(size_t)k * G + r] += acc;
+        for (int k = 0; k < N; k++) {
+            REAL *tmp = utmp + (size_t)k * G; /* per-k scratch row (thread-private under OpenMP) */
+            for (int r = 0; r < G; r++) tmp[r] = 0;
+            for (int b = 0; b < B; b++) {
+                const REAL hk = hp[(size_t)b * N + k];
+                const REAL *dgb = dg + (size_t)b * G;
+                for (int r = 0; r < G; r++) tmp[r] += dgb[r] * hk;
             }
+            for (int r = 0; r < G; r++) d.U[(size_t)k * G + r] += tmp[r];
+        }
         for (int b = 0; b < B; b++) {
             int xk = xi[t * B + b];
             if (xk >= 0)
@@ -336,7 +353,7 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
             for (int j = 0; j < N; j++)
                 dcnext[(size_t)b * N + j] = dc[(size_t)b * N + j] * gt[(size_t)b * G + 2 * N + j];
     }
-    free(dy); free(dh); free(dc); free(dg); free(dhnext); free(dcnext);
+    free(dy); free(dh); free(dc); free(dg); free(dhnext); free(dcnext); free(utmp);
 }
 
 /* m += d.*d ; p -= lr * d ./ sqrt(m + eps)   R/lstm.cc:261-272, over the whole flat block */
