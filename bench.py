@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- chars/sec through forward + BPTT + Adagrad on the BASELINE headline workload.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one training window: slide, forward over S-1 timesteps, loss, BPTT, [RCCL all-reduce of
+the flat gradient block], Adagrad -- everything the reference's i-loop does per iteration
+(OV/lstm_eigen_opt/lstm.cc:186-318).  Workload = BASELINE.json configs[2] (the config the metric is
+quoted on): hidden 512, window 100, batch 64 per GPU, fp32.  The corpus is synthetic (1e6 bytes drawn
+with enwik6's order-0 byte statistics): /root/reference does not exist on the GPU box and the
+throughput is content-independent.  For N > 1 the driver launches one rank per GPU with
+torch.distributed.run; torch is used ONLY as rendezvous plumbing (gloo: barrier, unique-id
+broadcast, max-over-ranks) -- the data path is the C-ABI library and RCCL inside it.
+
+Prints ONE JSON line on rank 0 (see the task contract), including
+  roofline     : the dominant kernel's algorithmic FLOP per launch / its HIP-event-timed duration
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference's loop) timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "eigen-lstm_amd"))
+
+METRIC = "chars/sec fwd+BPTT, enwik6 H=512 S=100 B=64, 1/2/4/8 GPU"
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
+
+
+def synthetic_text(n_bytes, seed=0):
+    hist = json.load(open(os.path.join(ROOT, "bench_data", "enwik6_byte_hist.json")))["counts"]
+    p = np.asarray(hist, np.float64)
+    p /= p.sum()
+    return np.random.RandomState(seed).choice(256, size=n_bytes, p=p).astype(np.uint8)
+
+
+def kernel_flops(N, S, B, M=256):
+    """algorithmic FLOP per launch of each MFMA kernel (one-hot structure exploited)."""
+    T = (S - 1) * B
+    return {
+        "fwd_step": 2.0 * 4 * N * N * B,                       # U * h_prev           R/lstm.cc:176
+        "bwd_step": 2.0 * 4 * N * N * B * (S - 2) / (S - 1),   # U^T * dg (none at t = S-1)  :255
+        "gemm_Y": 2.0 * M * N * T,                             # Why * h              :195
+        "gemm_DHy": 2.0 * M * N * T,                           # Why^T * dy           :228
+        "gemm_dWhy": 2.0 * M * N * T,                          # dy * h^T             :226
+        "gemm_dU": 2.0 * 4 * N * N * T,                        # dg * h_prev^T        :250
+        "fwd_persistent": 2.0 * 4 * N * N * B * (S - 1),
+        "bwd_persistent": 2.0 * 4 * N * N * B * (S - 2),
+    }
+
+
+def cpu_baseline(N, S, B, text, lr, budget_s=20.0):
+    """The oracle's trainer (a port of the reference loop) on this host, 1 thread, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    orc = Oracle("f32")
+    tr = orc.trainer(text, N, S, B, lr=lr, seed=1)
+    tr.epoch_reset()
+    tr.window()  # warm caches / page in
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.window()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    return {"value": (S - 1) * B * n / dt, "unit": "chars/s", "cores": 1, "kind": "port",
+            "sample": f"{n} window(s) of the same workload (N={N} S={S} B={B}) in {dt:.1f} s, "
+                      "oracle/lstm_ref.c -O3 -march=native, single thread like the reference build"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--seq", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=64, help="streams per GPU (weak scaling)")
+    ap.add_argument("--lr", type=float, default=0.01,
+                    help="Adagrad step; 0.1 (R/lstm.cc:59) overflows the unshifted softmax at hidden=512 batch=64 "
+                         "within ~100 windows unless the class_CUDA warm-up (lr=0 for 50*S windows) is used")
+    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-windows", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import lstm_hip
+
+    N, S, B, lr = args.hidden, args.seq, args.batch, args.lr
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # rendezvous plumbing only; no torch.cuda use
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    text = synthetic_text(1_000_000, seed=0)
+    L = lstm_hip.Lstm(N, S, B, device=local_rank, flags=args.flags)
+    rng = lstm_hip.MT19937Normal(1)
+    L.set_params(lstm_hip.init_params(rng, N))  # identical on every rank
+    srng = lstm_hip.MT19937Normal(1000 + rank)
+    L.set_state(1, srng.randn(N, B, 0.0, 0.1), srng.randn(N, B, 0.0, 0.1))  # becomes column 0 after the first slide
+    L.set_text(text)
+    L.set_cursors(lstm_hip.initial_cursors(len(text), S, B, stream0=rank * B, streams_total=world * B))
+    L.set_global_batch(world * B)
+    if world > 1:
+        ids = [lstm_hip.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        L.comm_init(ids[0], world, rank)
+
+    def barrier():
+        L.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    L.train_windows(args.warmup, lr, want_losses=False)
+    barrier()
+    t0 = time.perf_counter()
+    losses, dev_ms = L.train_windows(args.steps, lr, want_losses=True, want_time=True)
+    L.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+        lsum = torch.tensor(losses, dtype=torch.float64)
+        dist.all_reduce(lsum, op=dist.ReduceOp.SUM)
+        losses = lsum.numpy()
+    if not np.all(np.isfinite(losses)):
+        sys.exit(f"non-finite loss in the timed region: {losses[:5]}")
+
+    chars = (S - 1) * B * args.steps * world
+    value = chars / wall
+
+    # ---- per-kernel durations, HIP events on the library's own stream (separate short pass) ----
+    roofline = None
+    kstats = {}
+    if rank == 0 or world > 1:
+        L.reset_kernel_stats()
+        L.set_profiling(True)
+        L.train_windows(args.profile_windows, lr, want_losses=False)
+        L.set_profiling(False)
+        kstats = {k: v for k, v in L.kernel_stats().items() if v[0] > 0}
+    if rank == 0:
+        fl = kernel_flops(N, S, B)
+        mf = {k: v for k, v in kstats.items() if k in fl}
+        if mf:
+            dom = max(mf, key=lambda k: mf[k][1])
+            calls, ms = mf[dom]
+            avg_s = ms / calls * 1e-3
+            ach = fl[dom] / avg_s / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "avg_launch_us": round(avg_s * 1e6, 2), "flop_per_launch": fl[dom],
+                        "window_frac": round((24.0 * N * N + 6.0 * 256 * N) * (value / world) / 1e12
+                                             / PEAK_FP32_MFMA_TFLOPS, 4)}
+
+    if rank == 0:
+        out = {
+            "metric": METRIC, "value": round(value, 1), "unit": "chars/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (1e6 bytes, enwik6 order-0 byte statistics; random-init weights, seed 1)",
+            "config": {"workload": f"enwik6-shaped text, hidden={N} seq={S} batch={B}/GPU (global {B * world}), fp32, "
+                                   "stride-1 windows, Adagrad lr=%g" % lr,
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "engine": "step-kernels" if (args.flags & lstm_hip.STEP_KERNELS) else "default"},
+            "device_ms_per_step": round(dev_ms / args.steps, 4),
+            "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
+            "roofline": roofline,
+            "kernels_us": {k: [v[0] // max(args.profile_windows, 1), round(v[1] / v[0] * 1e3, 2)] for k, v in kstats.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, S, B, text, lr)
+        print(json.dumps(out), flush=True)
+    L.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,17 @@ void fwd_step(const float4 *Ufwd, const float *W, const float *bias, const float
 void bwd_step(const float4 *Ubwd, const float *DGnext /*null at t=S-1*/, const float *DHy_t, const float *G_t,
               const float *C_t, const float *Cprev, float *dcnext, float *DG_t, int N, int B, hipStream_t st);
 
+// ---- default engine: each recurrence of a window as ONE persistent launch (persistent.hip) ----
+// Weights stay in VGPRs; steps are chained by sc1 stores + sharded device-scope counters.
+// `cnt` must hold persistent_counter_bytes() zeroed bytes (separate regions for fwd and bwd);
+// `abortp` is one zeroed word that a timed-out spin sets.
+size_t persistent_counter_bytes(int S, int B);
+bool persistent_supported(int N, int B, int n_cus);
+void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
+                    const int32_t *xi, unsigned *cnt, unsigned *abortp, int N, int S, int B, bool fast, hipStream_t st);
+void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, unsigned *cnt,
+                    unsigned *abortp, int N, int S, int B, hipStream_t st);
+
 // ---- time-batched dense products (fp32 MFMA 32x32x2, LDS tiled) ------------------------------
 // C[M x Nn] = op(A)[M x K] * op(B)[K x Nn], column-major; TA: A is stored K x M; TB: B is stored Nn x K.
 // splits > 1 writes `splits` partial slabs into `slabs` (each M*Nn floats, ld = M); gemm_reduce
@@ -62,9 +73,10 @@ void dW_db(const float *DG /*[T][G4]*/, const int32_t *xi /*[T]*/, int T, int G4
 // ---- Adagrad over the flat block (R/lstm.cc:261-272; eps added in double, :25,46-48)
 void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, hipStream_t st);
 
-// ---- window builder on the device (OV/lstm_eigen_opt/lstm.cc:190-213), one thread per stream
-void slide_window(const uint8_t *text, uint64_t len, uint64_t *pos, int32_t *xi, int32_t *ti, int S, int B,
-                  hipStream_t st);
+// ---- window builder on the device (OV/lstm_eigen_opt/lstm.cc:190-213): x/target rings + flat copies,
+//      cursor advance, and the h/c carry (column 1 -> column 0).  Single workgroup.
+void slide_window(const uint8_t *text, uint64_t len, uint64_t *pos, int32_t *Xr, int32_t *Tr, int32_t *headp,
+                  int32_t *xi, int32_t *ti, float *H, float *C, int S, int B, int N, hipStream_t st);
 
 // ---- B = 1 recurrence for the evaluator / sampler (OV/lstm_eigen_class_CUDA/lstm.cc:578-720)
 void eval_bits(const float *P, int N, const uint8_t *text, uint64_t len, double *out_bits_sum, float *scratch,

@@ -96,26 +96,51 @@ __global__ __launch_bounds__(256) void k_fwd_step(const float4 *__restrict__ Ufw
     const int nk4 = N / 16, G4 = 4 * N;
     const int nct = (B + 15) / 16;
     const float4 *Ua = Ufwd + (size_t)jb * nk4 * 64 + l;
+    constexpr int CH = 8; // k4-steps per operand chunk: 16 float4 in flight per lane
     for (int ct = w; ct < nct; ct += 4) {
         const int col = ct * 16 + (l & 15);
         const int colc = col < B ? col : B - 1;
         const float *hp = Hprev + (size_t)colc * N + 4 * (l >> 4);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int k4 = 0; k4 < nk4; k4 += 2) {
-            float4 a0 = Ua[(size_t)k4 * 64];
-            float4 b0 = *reinterpret_cast<const float4 *>(hp + 16 * k4);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
-            if (k4 + 1 < nk4) {
-                float4 a1 = Ua[(size_t)(k4 + 1) * 64];
-                float4 b1 = *reinterpret_cast<const float4 *>(hp + 16 * (k4 + 1));
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
+        float4 a[CH], b[CH], an[CH], bn[CH];
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int k4 = i < nk4 ? i : nk4 - 1;
+            a[i] = Ua[(size_t)k4 * 64];
+            b[i] = *reinterpret_cast<const float4 *>(hp + 16 * k4);
+        }
+        for (int c0 = 0; c0 < nk4; c0 += CH) {
+            const bool more = c0 + CH < nk4;
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < CH; i++) {
+                    const int k4 = c0 + CH + i < nk4 ? c0 + CH + i : nk4 - 1;
+                    an[i] = Ua[(size_t)k4 * 64];
+                    bn[i] = *reinterpret_cast<const float4 *>(hp + 16 * k4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                if (c0 + i < nk4) {
+                    if (i & 1) {
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc1, 0, 0, 0);
+                    } else {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc0, 0, 0, 0);
+                    }
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < CH; i++) {
+                    a[i] = an[i];
+                    b[i] = bn[i];
+                }
             }
         }
         if (col < B) {
@@ -177,21 +202,46 @@ __global__ __launch_bounds__(256) void k_bwd_step(const float4 *__restrict__ Ubw
         const float4 *Ua = Ubwd + ((size_t)kb * nr4 + (size_t)w * per) * 64 + l;
         const float *dgp = DGnext + (size_t)colc * G4 + 16 * (w * per) + 4 * (l >> 4);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int r4 = 0; r4 < per; r4 += 2) {
-            float4 a0 = Ua[(size_t)r4 * 64];
-            float4 b0 = *reinterpret_cast<const float4 *>(dgp + 16 * r4);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
-            if (r4 + 1 < per) {
-                float4 a1 = Ua[(size_t)(r4 + 1) * 64];
-                float4 b1 = *reinterpret_cast<const float4 *>(dgp + 16 * (r4 + 1));
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
+        constexpr int CH = 8;
+        float4 a[CH], b[CH], an[CH], bn[CH];
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int r4 = i < per ? i : per - 1;
+            a[i] = Ua[(size_t)r4 * 64];
+            b[i] = *reinterpret_cast<const float4 *>(dgp + 16 * r4);
+        }
+        for (int c0 = 0; c0 < per; c0 += CH) {
+            const bool more = c0 + CH < per;
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < CH; i++) {
+                    const int r4 = c0 + CH + i < per ? c0 + CH + i : per - 1;
+                    an[i] = Ua[(size_t)r4 * 64];
+                    bn[i] = *reinterpret_cast<const float4 *>(dgp + 16 * r4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                if (c0 + i < per) {
+                    if (i & 1) {
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc1, 0, 0, 0);
+                    } else {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc0, 0, 0, 0);
+                    }
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < CH; i++) {
+                    a[i] = an[i];
+                    b[i] = bn[i];
+                }
             }
         }
 #pragma unroll
@@ -452,15 +502,35 @@ void softmax_loss_dy(float *Y, float *P, const float *by, const int32_t *ti, flo
     hipLaunchKernelGGL(k_softmax_loss_dy, dim3(blocks), dim3(256), 0, st, Y, P, by, ti, colloss, dby_part, T);
 }
 
-// dby = rowsum(dY) (R/lstm.cc:227): sum the per-wave partials in order
-__global__ __launch_bounds__(256) void k_dby_finish(const float *__restrict__ part, int n_parts, float *__restrict__ dby) {
-    const int m = threadIdx.x;
-    float s = 0.0f;
-    for (int p = 0; p < n_parts; p++) s += part[(size_t)p * 256 + m];
-    dby[m] = s;
+// dby = rowsum(dY) (R/lstm.cc:227): fold the per-wave partials.  1024 threads = 64 float4 row groups
+// x 16 phases; phase q sums partials q, q+16, ... in order, then the 16 phase sums are added in order.
+__global__ __launch_bounds__(1024) void k_dby_finish(const float *__restrict__ part, int n_parts, float *__restrict__ dby) {
+    __shared__ float4 red[16][64];
+    const int m4 = threadIdx.x & 63, q = threadIdx.x >> 6;
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int p = q; p < n_parts; p += 16) {
+        const float4 v = reinterpret_cast<const float4 *>(part + (size_t)p * 256)[m4];
+        s.x += v.x;
+        s.y += v.y;
+        s.z += v.z;
+        s.w += v.w;
+    }
+    red[q][m4] = s;
+    __syncthreads();
+    if (q == 0) {
+        float4 t = red[0][m4];
+        for (int i = 1; i < 16; i++) {
+            t.x += red[i][m4].x;
+            t.y += red[i][m4].y;
+            t.z += red[i][m4].z;
+            t.w += red[i][m4].w;
+        }
+        reinterpret_cast<float4 *>(dby)[m4] = t;
+    }
 }
 void dby_finish(const float *dby_part, int n_parts, float *dby, hipStream_t st) {
-    hipLaunchKernelGGL(k_dby_finish, dim3(1), dim3(256), 0, st, dby_part, n_parts, dby);
+    hipLaunchKernelGGL(k_dby_finish, dim3(1), dim3(1024), 0, st, dby_part, n_parts, dby);
 }
 
 // loss += surprisals.sum() / B per step (OV/lstm_eigen_opt/lstm.cc:249): float sum over the columns
@@ -500,11 +570,26 @@ __global__ __launch_bounds__(DW_THREADS) void k_dW_db(const float *__restrict__ 
     for (int i = tid; i < 257 * DW_THREADS; i += DW_THREADS) acc[i] = 0.0f;
     __syncthreads();
     const float *src = DG + r0 + r;
-    for (int col = q; col < T; col += DW_COPIES) {
+    constexpr int UN = 8; // columns in flight per thread
+    int col = q;
+    for (; col + (UN - 1) * DW_COPIES < T; col += UN * DW_COPIES) {
+        int v[UN];
+        float val[UN];
+#pragma unroll
+        for (int i = 0; i < UN; i++) {
+            v[i] = xi[col + i * DW_COPIES];
+            val[i] = src[(size_t)(col + i * DW_COPIES) * G4];
+        }
+#pragma unroll
+        for (int i = 0; i < UN; i++) {
+            const int vv = v[i] < 0 ? 256 : v[i];
+            atomicAdd(&acc[vv * DW_THREADS + tid], val[i]); // ds_add_f32 on a word private to this thread
+        }
+    }
+    for (; col < T; col += DW_COPIES) {
         int v = xi[col];
         v = v < 0 ? 256 : v;
-        const float val = src[(size_t)col * G4];
-        atomicAdd(&acc[v * DW_THREADS + tid], val); // ds_add_f32, private word
+        atomicAdd(&acc[v * DW_THREADS + tid], src[(size_t)col * G4]);
     }
     __syncthreads();
     // fold the 8 phases in fixed order; keep bucket totals in slot 0 for the db pass
@@ -565,29 +650,50 @@ void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, hipStrea
 }
 
 // ------------------------------------------------------------------------------------------------
-// slide_window: OV/lstm_eigen_opt/lstm.cc:190-213 on indices, one thread per stream.
-//   event = text[pos]; pos++; wrap to S; shift x,target left; target[S-1] = event; x[S-1] = target[S-2]
-// (the h/c part of the slide is a column copy done by the caller)
+// slide_window: OV/lstm_eigen_opt/lstm.cc:190-213 on indices.  x and target are kept as rings of S
+// rows (row s of the window lives in ring row (head+s)%S), so "shift every column left by one" is
+// head++ and the new column overwrites the slot of the column that fell off -- exactly the
+// reference's result, including row 0.  One workgroup:
+//   event = text[pos]; pos++ (wrap to S)                              opt:192-197
+//   target[S-1] = onehot(event); x[S-1] = target[S-2]                 opt:211-212
+//   flat xi/ti (what the kernels read) are rewritten from the rings
+//   h[0] <- h[1], c[0] <- c[1]                                        opt:205-206
 // ------------------------------------------------------------------------------------------------
-__global__ void k_slide_window(const uint8_t *__restrict__ text, uint64_t len, uint64_t *__restrict__ pos,
-                               int32_t *__restrict__ xi, int32_t *__restrict__ ti, int S, int B) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    uint64_t p = pos[b];
-    const int event = text[p];
-    p++;
-    if (p >= len) p = (uint64_t)S;
-    pos[b] = p;
-    for (int s = 1; s < S; s++) {
-        xi[(s - 1) * B + b] = xi[s * B + b];
-        ti[(s - 1) * B + b] = ti[s * B + b];
+__global__ __launch_bounds__(1024) void k_slide_window(const uint8_t *__restrict__ text, uint64_t len,
+                                                       uint64_t *__restrict__ pos, int32_t *__restrict__ Xr,
+                                                       int32_t *__restrict__ Tr, int32_t *__restrict__ headp,
+                                                       int32_t *__restrict__ xi, int32_t *__restrict__ ti,
+                                                       float *__restrict__ H, float *__restrict__ C, int S, int B,
+                                                       int NB4) {
+    const int head = (*headp + 1) % S;
+    const int last = (head + S - 1) % S, prev = (head + S - 2) % S;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        uint64_t p = pos[b];
+        const int event = text[p];
+        p++;
+        if (p >= len) p = (uint64_t)S;
+        pos[b] = p;
+        Tr[last * B + b] = event;
+        Xr[last * B + b] = Tr[prev * B + b];
     }
-    ti[(S - 1) * B + b] = event;
-    xi[(S - 1) * B + b] = ti[(S - 2) * B + b];
+    // carry: column 0 of the next window is column 1 of this one
+    for (int i = threadIdx.x; i < NB4; i += blockDim.x) {
+        reinterpret_cast<float4 *>(H)[i] = reinterpret_cast<const float4 *>(H)[NB4 + i];
+        reinterpret_cast<float4 *>(C)[i] = reinterpret_cast<const float4 *>(C)[NB4 + i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < S * B; i += blockDim.x) {
+        const int t = i / B, b = i - t * B;
+        const int row = (head + t) % S;
+        xi[i] = Xr[row * B + b];
+        ti[i] = Tr[row * B + b];
+    }
+    if (threadIdx.x == 0) *headp = head;
 }
-void slide_window(const uint8_t *text, uint64_t len, uint64_t *pos, int32_t *xi, int32_t *ti, int S, int B,
-                  hipStream_t st) {
-    hipLaunchKernelGGL(k_slide_window, dim3((B + 63) / 64), dim3(64), 0, st, text, len, pos, xi, ti, S, B);
+void slide_window(const uint8_t *text, uint64_t len, uint64_t *pos, int32_t *Xr, int32_t *Tr, int32_t *headp,
+                  int32_t *xi, int32_t *ti, float *H, float *C, int S, int B, int N, hipStream_t st) {
+    hipLaunchKernelGGL(k_slide_window, dim3(1), dim3(1024), 0, st, text, len, pos, Xr, Tr, headp, xi, ti, H, C, S, B,
+                       N * B / 4);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -40,11 +40,11 @@ int fail(int code, const char *fmt, ...) {
 
 enum KernelId {
     K_PACK_U, K_FWD_STEP, K_GEMM_Y, K_SOFTMAX, K_LOSS, K_GEMM_DHY, K_BWD_STEP, K_GEMM_DWHY, K_GEMM_DU, K_DW_DB,
-    K_DBY, K_ADAGRAD, K_SLIDE, K_ALLREDUCE, K_COUNT
+    K_DBY, K_ADAGRAD, K_SLIDE, K_ALLREDUCE, K_FWD_PERSIST, K_BWD_PERSIST, K_COUNT
 };
 const char *const kKernelNames[K_COUNT] = {
     "pack_U", "fwd_step", "gemm_Y", "softmax_loss_dy", "loss_reduce", "gemm_DHy", "bwd_step", "gemm_dWhy", "gemm_dU",
-    "dW_db", "dby_finish", "adagrad", "slide", "allreduce"};
+    "dW_db", "dby_finish", "adagrad", "slide", "allreduce", "fwd_persistent", "bwd_persistent"};
 
 // ---- RCCL, loaded on first use so single-GPU users never touch it --------------------------
 struct UniqueId {
@@ -92,7 +92,8 @@ struct lstm_hip_ctx {
     float *dcnext = nullptr, *colloss = nullptr, *dby_part = nullptr, *slabs = nullptr;
     int n_dby_parts = 0;
     int splits_dWhy = 1, splits_dU = 1;
-    int32_t *xi = nullptr, *ti = nullptr;
+    int32_t *xi = nullptr, *ti = nullptr;            // flat [S][B] indices the kernels read
+    int32_t *Xr = nullptr, *Tr = nullptr, *head = nullptr; // ring form kept by the device-side slide
     double *d_loss = nullptr;
     double *d_losses = nullptr;
     int64_t losses_cap = 0;
@@ -101,6 +102,10 @@ struct lstm_hip_ctx {
     uint64_t *pos = nullptr;
     int32_t global_B = 0;
     bool fwd_done = false;
+    bool persistent = false;     // default engine; false = one launch per timestep
+    unsigned *cnt = nullptr;     // [2][persistent_counter_bytes]: fwd region, bwd region
+    unsigned *abortp = nullptr;  // set by a timed-out spin inside a persistent kernel
+    size_t cnt_bytes = 0;
 
     void *comm = nullptr;
     int nranks = 1, rank = 0;
@@ -155,6 +160,19 @@ int check(lstm_hip_ctx *h) {
         if (rc_) return rc_; \
     } while (0)
 
+// after a synchronisation point: did a persistent kernel give up on a hand-off?
+int check_abort(lstm_hip_ctx *h) {
+    if (!h->persistent) return 0;
+    unsigned flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, h->abortp, sizeof(unsigned), hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
+    if (flag != 0) {
+        HIP_TRY(hipMemsetAsync(h->abortp, 0, sizeof(unsigned), h->st));
+        return fail(LSTM_HIP_ESTATE, "a persistent recurrence kernel timed out waiting for a hand-off (results invalid)");
+    }
+    return 0;
+}
+
 int do_forward(lstm_hip_ctx *h) {
     const int N = h->cfg.N, B = h->cfg.B, S = h->cfg.S, G4 = 4 * N;
     const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
@@ -162,6 +180,11 @@ int do_forward(lstm_hip_ctx *h) {
         RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd, h->Ubwd, N, h->st));
         h->packed = true;
     }
+    if (h->persistent) {
+        HIP_TRY(hipMemsetAsync(h->cnt, 0, h->cnt_bytes, h->st));
+        RUN(K_FWD_PERSIST, fwd_persistent(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->cnt,
+                                          h->abortp, N, S, B, fast, h->st));
+    } else
     for (int t = 1; t < S; t++) {
         RUN(K_FWD_STEP, fwd_step(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H + (size_t)(t - 1) * N * B,
                                  h->C + (size_t)(t - 1) * N * B, h->H + (size_t)t * N * B, h->C + (size_t)t * N * B,
@@ -185,11 +208,17 @@ int do_backward(lstm_hip_ctx *h) {
     // DHy = Why^T * dY                 R/lstm.cc:228, all steps
     RUN(K_GEMM_DHY, gemm(true, false, N, T, 256, h->P + h->pl.Why, 256, dY, 256, h->DHy + (size_t)N * B, N, 1, nullptr,
                          h->st));
+    if (h->persistent) {
+        unsigned *cb = h->cnt + h->cnt_bytes / sizeof(unsigned);
+        HIP_TRY(hipMemsetAsync(cb, 0, h->cnt_bytes, h->st));
+        RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, cb, h->abortp, N, S, B, h->st));
+    } else {
     HIP_TRY(hipMemsetAsync(h->dcnext, 0, sizeof(float) * N * B, h->st)); // R/lstm.cc:216-217
     for (int t = S - 1; t >= 1; t--) {
         RUN(K_BWD_STEP, bwd_step(h->Ubwd, t < S - 1 ? h->DG + (size_t)(t + 1) * G4 * B : nullptr,
                                  h->DHy + (size_t)t * N * B, h->G + (size_t)t * G4 * B, h->C + (size_t)t * N * B,
                                  h->C + (size_t)(t - 1) * N * B, h->dcnext, h->DG + (size_t)t * G4 * B, N, B, h->st));
+    }
     }
     // dWhy = dY * H[1..]^T             R/lstm.cc:226
     RUN(K_GEMM_DWHY, gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256,
@@ -282,10 +311,19 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
     }
     ALLOC(h->xi, S * B);
     ALLOC(h->ti, S * B);
+    ALLOC(h->Xr, S * B);
+    ALLOC(h->Tr, S * B);
+    ALLOC(h->head, 1);
     HIP_TRY(hipMemset(h->xi, 0xff, sizeof(int32_t) * S * B)); // -1: all-zero columns (opt:122,125)
     HIP_TRY(hipMemset(h->ti, 0xff, sizeof(int32_t) * S * B));
+    HIP_TRY(hipMemset(h->Xr, 0xff, sizeof(int32_t) * S * B));
+    HIP_TRY(hipMemset(h->Tr, 0xff, sizeof(int32_t) * S * B));
     ALLOC(h->d_loss, 1);
     ALLOC(h->pos, B);
+    h->cnt_bytes = persistent_counter_bytes((int)S, (int)B);
+    ALLOC(h->cnt, 2 * h->cnt_bytes / sizeof(unsigned));
+    ALLOC(h->abortp, 4);
+    h->persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) && persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount);
     HIP_TRY(hipDeviceSynchronize());
     *out = h;
     return 0;
@@ -297,7 +335,7 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     (void)hipStreamSynchronize(h->st);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
-                    h->colloss, h->dby_part, h->slabs, h->xi, h->ti, h->d_loss, h->d_losses, h->text, h->pos};
+                    h->colloss, h->dby_part, h->slabs, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -324,7 +362,7 @@ int lstm_hip_get_params(lstm_hip_t *h, int which, float *host_block) {
     if (!src || !host_block) return fail(LSTM_HIP_EINVAL, "get_params: bad block id %d or null pointer", which);
     HIP_TRY(hipMemcpyAsync(host_block, src, sizeof(float) * h->pl.total, hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
-    return 0;
+    return check_abort(h);
 }
 
 int lstm_hip_set_state(lstm_hip_t *h, int32_t t, const float *h_t, const float *c_t) {
@@ -364,6 +402,9 @@ int lstm_hip_set_window(lstm_hip_t *h, const int32_t *xi, const int32_t *ti) {
             return fail(LSTM_HIP_EINVAL, "set_window: index %d/%d at %zu is >= %d", xi[i], ti[i], i, LSTM_HIP_VOCAB);
     HIP_TRY(hipMemcpyAsync(h->xi, xi, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->st));
     HIP_TRY(hipMemcpyAsync(h->ti, ti, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->st));
+    HIP_TRY(hipMemcpyAsync(h->Xr, xi, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->st)); // rings, head = 0
+    HIP_TRY(hipMemcpyAsync(h->Tr, ti, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->st));
+    HIP_TRY(hipMemsetAsync(h->head, 0, sizeof(int32_t), h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
     return 0;
 }
@@ -380,6 +421,9 @@ int lstm_hip_reset_window(lstm_hip_t *h) {
     const size_t n = (size_t)h->cfg.S * h->cfg.B;
     HIP_TRY(hipMemsetAsync(h->xi, 0xff, sizeof(int32_t) * n, h->st));
     HIP_TRY(hipMemsetAsync(h->ti, 0xff, sizeof(int32_t) * n, h->st));
+    HIP_TRY(hipMemsetAsync(h->Xr, 0xff, sizeof(int32_t) * n, h->st));
+    HIP_TRY(hipMemsetAsync(h->Tr, 0xff, sizeof(int32_t) * n, h->st));
+    HIP_TRY(hipMemsetAsync(h->head, 0, sizeof(int32_t), h->st));
     return 0;
 }
 
@@ -406,7 +450,7 @@ int lstm_hip_loss(lstm_hip_t *h, double *loss_bits) {
     RUN(K_LOSS, loss_reduce(h->colloss, h->cfg.S - 1, h->cfg.B, h->global_B, h->d_loss, h->st));
     HIP_TRY(hipMemcpyAsync(loss_bits, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
-    return 0;
+    return check_abort(h);
 }
 int lstm_hip_backward(lstm_hip_t *h) {
     CHECK(h);
@@ -499,9 +543,9 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
         HIP_TRY(hipEventRecord(e0, h->st));
     }
     for (int64_t i = 0; i < count; i++) {
-        RUN(K_SLIDE, slide_window(h->text, h->text_len, h->pos, h->xi, h->ti, h->cfg.S, h->cfg.B, h->st));
-        int rc = slide_state(h);
-        if (rc) return rc;
+        RUN(K_SLIDE, slide_window(h->text, h->text_len, h->pos, h->Xr, h->Tr, h->head, h->xi, h->ti, h->H, h->C,
+                                  h->cfg.S, h->cfg.B, h->cfg.N, h->st));
+        int rc = 0;
         if ((rc = do_forward(h))) return rc;
         RUN(K_LOSS, loss_reduce(h->colloss, h->cfg.S - 1, h->cfg.B, h->global_B, h->d_losses + i, h->st));
         if ((rc = do_backward(h))) return rc;
@@ -518,7 +562,7 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
     if (losses && count > 0)
         HIP_TRY(hipMemcpyAsync(losses, h->d_losses, sizeof(double) * count, hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
-    return 0;
+    return check_abort(h);
 }
 
 int lstm_hip_eval_bits(lstm_hip_t *h, const uint8_t *text, size_t len, double *bits_per_char) {
@@ -563,7 +607,7 @@ int lstm_hip_sample(lstm_hip_t *h, float *h0, float *c0, const double *u, int32_
 int lstm_hip_synchronize(lstm_hip_t *h) {
     CHECK(h);
     HIP_TRY(hipStreamSynchronize(h->st));
-    return 0;
+    return check_abort(h);
 }
 int lstm_hip_set_profiling(lstm_hip_t *h, int32_t on) {
     if (!h) return fail(LSTM_HIP_EINVAL, "null handle");

@@ -1,0 +1,378 @@
+// persistent.hip -- the two recurrences of a window as ONE launch each (gfx950).
+//
+// Why: a timestep of the reference is  g = U*h_prev (+gather, bias) -> gates -> c,h  (R/lstm.cc:176-192)
+// and, going back,  dhnext = U^T*dg -> dc,dg (R/lstm.cc:228-256).  At batch 64 that is ~134 MFLOP,
+// <1 us of MFMA, and the only true dependency between steps is the 128 KB h (or 512 KB dg) vector.
+// Launching one kernel per step re-reads the recurrent weights from L2 every step (32 MB/step across
+// the chip, ~10 us/step measured) and pays a kernel boundary per step.  Here the weights stay in
+// REGISTERS for the whole window and the steps are chained inside the launch by a device-scope
+// hand-off.
+//
+// Decomposition (forward): workgroup (p, g) owns hidden units 4p..4p+3 -- one 16-row MFMA tile whose
+// rows are (unit, gate) so a lane ends up with i,o,f,u of one unit in its 4 accumulator registers --
+// for batch-column group g (16 columns).  Its 4 waves split K = N; each keeps its quarter of the
+// tile's U rows as 16x16x4 A-fragments in VGPRs.  Column groups are independent recurrences, so
+// the (p, g) workgroups of different g that share a CU overlap each other's hand-off latency.
+//
+// Hand-off (cdna_hip_programming.md Guideline 16, counter form): the producing wave stores its slice
+// of h_t with sc1 (write-through) 16-byte stores, drains them (s_waitcnt vmcnt(0)), then ONE lane
+// does a relaxed agent-scope atomic add on a counter sharded 8 ways (cnt[t][g][p&7]) so arrivals do
+// not serialise on one address.  A consumer's wave 0 polls the 8 shards with sc1 loads until every
+// shard has all its arrivals, a workgroup barrier follows, and only then does any wave read h_t, with
+// sc1 loads (never through L1).  Counters are zeroed by a memset node before every launch.  Every
+// spin is bounded; on time-out a global abort word makes every workgroup leave, and the host reports it.
+//
+// Residency: all workgroups must be co-resident (they wait on each other); the host checks the grid
+// against the occupancy of the device and falls back to the per-step engine otherwise.
+#include "kernels.h"
+
+namespace lstmk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#pragma clang fp contract(off)
+template <bool FAST> __device__ __forceinline__ float p_sigm(float x) {
+    if (FAST) return __frcp_rn(1.0f + __expf(-x));
+    return 1.0f / (1.0f + expf(-x));
+}
+template <bool FAST> __device__ __forceinline__ float p_tanh(float x) {
+    if (FAST) return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
+    return tanhf(x);
+}
+
+constexpr int CNT_STRIDE = 16;       // uints between shards: one 64-byte line each
+constexpr int SPIN_LIMIT = 1 << 21;  // bounded spin; ~seconds
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, size_t bytes) {
+    const unsigned n = bytes > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ float4 ld_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16); // aux 16 = sc1
+    float4 f;
+    f.x = __uint_as_float(v.x);
+    f.y = __uint_as_float(v.y);
+    f.z = __uint_as_float(v.z);
+    f.w = __uint_as_float(v.w);
+    return f;
+}
+__device__ __forceinline__ void st_sc1(float4 f, __amdgpu_buffer_rsrc_t r, int byte_off) {
+    u32x4 v;
+    v.x = __float_as_uint(f.x);
+    v.y = __float_as_uint(f.y);
+    v.z = __float_as_uint(f.z);
+    v.w = __float_as_uint(f.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 16);
+}
+
+// wave-level wait until all `n_prod` producers (sharded by id & 7) have arrived at `cp`.
+// Returns false on time-out / abort.  Called by one whole wave.
+__device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, unsigned *abortp, int lane) {
+    const unsigned expect = lane < 8 ? (unsigned)((n_prod - lane + 7) / 8) : 0u;
+    for (int spins = 0;; spins++) {
+        unsigned v = 0;
+        if (lane < 8) v = __hip_atomic_load(cp + lane * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v >= expect)) return true;
+        if (spins > SPIN_LIMIT) break;
+        if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane == 0) __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward recurrence, t = 1..S-1, N = 64*NK4W.  grid (N/4, ceil(B/16)), 256 threads.
+// ------------------------------------------------------------------------------------------------
+template <int NK4W, bool FAST>
+__global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict__ Ufwd, const float *__restrict__ W,
+                                                        const float *__restrict__ bias, float *H, float *__restrict__ C,
+                                                        float *__restrict__ G, const int32_t *__restrict__ xi,
+                                                        unsigned *cnt, unsigned *abortp, int S, int B) {
+    constexpr int N = 64 * NK4W, G4 = 4 * N, nk4 = N / 16;
+    __shared__ float red[4 * 4 * 64];
+    __shared__ int s_abort;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int p = blockIdx.x, g = blockIdx.y, NB = gridDim.x, NG = gridDim.y;
+    const int q = l >> 4, c = l & 15;
+    const int col = 16 * g + c, colc = col < B ? col : B - 1;
+    const int j = 4 * p + q;
+
+    float4 a[NK4W];
+#pragma unroll
+    for (int i = 0; i < NK4W; i++) a[i] = Ufwd[((size_t)p * nk4 + w * NK4W + i) * 64 + l];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (w == 0) {
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
+        cprev = C[(size_t)colc * N + j];
+    }
+    const __amdgpu_buffer_rsrc_t rH = make_rsrc(H, (size_t)S * N * B * sizeof(float));
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+
+    for (int t = 1; t < S; t++) {
+        float wx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w == 0) {
+            const int x = xi[t * B + colc];
+            if (x >= 0) {
+#pragma unroll
+                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
+            }
+            if (t > 1) {
+                const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * 8 * CNT_STRIDE;
+                if (!wait_arrivals(cp, NB, abortp, l) && l == 0) s_abort = 1;
+            }
+        }
+        __syncthreads();
+        if (s_abort) return;
+
+        const int off = (int)((((size_t)(t - 1) * B + colc) * N + 16 * (w * NK4W) + 4 * q) * sizeof(float));
+        float4 b[NK4W];
+#pragma unroll
+        for (int i = 0; i < NK4W; i++) b[i] = ld_sc1(rH, off + 64 * i);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NK4W; i++) {
+            if (i & 1) {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc1, 0, 0, 0);
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
+        __syncthreads();
+
+        if (w == 0) {
+            float pre[4];
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) {
+                const float uh = ((red[(0 * 4 + gt) * 64 + l] + red[(1 * 4 + gt) * 64 + l]) + red[(2 * 4 + gt) * 64 + l]) +
+                                 red[(3 * 4 + gt) * 64 + l];
+                pre[gt] = (wx[gt] + uh) + bs[gt]; // R/lstm.cc:176
+            }
+            const float ig = p_sigm<FAST>(pre[0]), og = p_sigm<FAST>(pre[1]), fg = p_sigm<FAST>(pre[2]); // :179
+            const float ug = p_tanh<FAST>(pre[3]);                                                        // :182
+            const float cv = p_tanh<FAST>(ig * ug + fg * cprev);                                          // :185-189
+            const float hv = og * cv;                                                                     // :192
+            cprev = cv;
+            // publish h_t first (it is the only thing the next step of other workgroups waits for)
+            float4 h4;
+            h4.x = __shfl(hv, c, 64);
+            h4.y = __shfl(hv, 16 + c, 64);
+            h4.z = __shfl(hv, 32 + c, 64);
+            h4.w = __shfl(hv, 48 + c, 64);
+            if (q == 0 && col < B) st_sc1(h4, rH, (int)((((size_t)t * B + col) * N + 4 * p) * sizeof(float)));
+            if (t + 1 < S) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (l == 0)
+                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * 8 + (p & 7)) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (col < B) {
+                float *gc = G + ((size_t)t * B + col) * G4 + j;
+                gc[0] = ig;
+                gc[N] = og;
+                gc[2 * N] = fg;
+                gc[3 * N] = ug;
+                C[((size_t)t * B + col) * N + j] = cv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward recurrence, t = S-1..1, N = 32*NR4W.  grid (N/16, ceil(B/16)), 512 threads.
+// Workgroup (kb, g) owns hidden units 16kb..16kb+15 for column group g: one 16x16 tile of
+// dhnext = U^T * dg[t+1] (R/lstm.cc:255) with K = 4N split over its 8 waves (U^T A-fragments in
+// VGPRs), then one thread per (unit, column) does R/lstm.cc:228-247,256 and dg[t] is published.
+// ------------------------------------------------------------------------------------------------
+template <int NR4W>
+__global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict__ Ubwd, float *DG,
+                                                        const float *__restrict__ DHy, const float *__restrict__ G,
+                                                        const float *__restrict__ C, unsigned *cnt, unsigned *abortp,
+                                                        int S, int B) {
+    constexpr int N = 32 * NR4W, G4 = 4 * N, nr4 = N / 4;
+    __shared__ float red[8 * 4 * 64];
+    __shared__ __attribute__((aligned(16))) float stage[16 * 4 * 16];
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int kb = blockIdx.x, g = blockIdx.y, NBK = gridDim.x, NG = gridDim.y;
+    const int q = l >> 4;
+    const int mcol = 16 * g + (l & 15), mcolc = mcol < B ? mcol : B - 1; // MFMA B-operand column
+    // epilogue role (threads 0..255): unit jj, column cc
+    const int jj = tid & 15, cc = (tid >> 4) & 15;
+    const int ecol = 16 * g + cc, ecolc = ecol < B ? ecol : B - 1;
+    const int j = 16 * kb + jj;
+    // store role (threads 0..255): float4 of 4 consecutive units for (column sc, gate sg)
+    const int sc = (tid >> 4) & 15, sg = (tid >> 2) & 3, sq = tid & 3;
+
+    float4 a[NR4W];
+#pragma unroll
+    for (int i = 0; i < NR4W; i++) a[i] = Ubwd[((size_t)kb * nr4 + w * NR4W + i) * 64 + l];
+    const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG, (size_t)S * G4 * B * sizeof(float));
+    float dcn = 0.0f; // dcnext, R/lstm.cc:217
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+
+    for (int t = S - 1; t >= 1; t--) {
+        // operands of the elementwise part do not depend on the chain: fetch them first
+        float ig = 0.f, og = 0.f, fg = 0.f, ug = 0.f, cv = 0.f, cp = 0.f, dhy = 0.f;
+        if (tid < 256) {
+            const float *gc = G + ((size_t)t * B + ecolc) * G4 + j;
+            ig = gc[0];
+            og = gc[N];
+            fg = gc[2 * N];
+            ug = gc[3 * N];
+            cv = C[((size_t)t * B + ecolc) * N + j];
+            cp = C[((size_t)(t - 1) * B + ecolc) * N + j];
+            dhy = DHy[((size_t)t * B + ecolc) * N + j];
+        }
+        const bool has_next = t < S - 1;
+        if (has_next && w == 0) {
+            const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * 8 * CNT_STRIDE;
+            if (!wait_arrivals(cpn, NBK, abortp, l) && l == 0) s_abort = 1;
+        }
+        __syncthreads();
+        if (s_abort) return;
+
+        float dhn = 0.0f;
+        if (has_next) {
+            const int off = (int)((((size_t)(t + 1) * B + mcolc) * G4 + 16 * (w * NR4W) + 4 * q) * sizeof(float));
+            float4 b[NR4W];
+#pragma unroll
+            for (int i = 0; i < NR4W; i++) b[i] = ld_sc1(rDG, off + 64 * i);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NR4W; i++) {
+                if (i & 1) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc1, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
+            __syncthreads();
+            if (tid < 256) {
+                // D[row = 4*(lane>>4) + reg][col = lane&15]  ->  unit jj lives in lane (jj>>2)*16 + cc, reg jj&3
+                const int src = (jj >> 2) * 16 + cc, reg = jj & 3;
+#pragma unroll
+                for (int ww = 0; ww < 8; ww++) dhn += red[(ww * 4 + reg) * 64 + src];
+            }
+        }
+        if (tid < 256) {
+            const float dh = dhy + dhn;                         // R/lstm.cc:228
+            float dcv = dh * og + dcn;                          // :233
+            dcv = dcv * (1.0f - cv * cv);                       // :235
+            const float d_o = (dh * cv) * (og * (1.0f - og));   // :238,244
+            const float d_i = (dcv * ug) * (ig * (1.0f - ig));  // :239,244
+            const float d_f = (dcv * cp) * (fg * (1.0f - fg));  // :240,244
+            const float d_u = (dcv * ig) * (1.0f - ug * ug);    // :241,247
+            dcn = dcv * fg;                                     // :256
+            float *sp = stage + (cc * 4) * 16 + jj;
+            sp[0] = d_i;
+            sp[16] = d_o;
+            sp[32] = d_f;
+            sp[48] = d_u;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int scol = 16 * g + sc;
+            if (scol < B) {
+                const float4 v = *reinterpret_cast<const float4 *>(stage + (sc * 4 + sg) * 16 + 4 * sq);
+                st_sc1(v, rDG, (int)((((size_t)t * B + scol) * G4 + sg * N + 16 * kb + 4 * sq) * sizeof(float)));
+            }
+        }
+        if (t > 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the signal
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * 8 + (kb & 7)) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+size_t persistent_counter_bytes(int S, int B) {
+    const int NG = (B + 15) / 16;
+    return (size_t)(S + 1) * NG * 8 * CNT_STRIDE * sizeof(unsigned);
+}
+
+template <class K> static int blocks_per_cu(K kernel, int threads) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess) return 0;
+    return n;
+}
+
+#define FWD_CASES(X) X(1) X(2) X(4) X(8) X(16)
+#define BWD_CASES(X) X(2) X(4) X(8) X(16) X(32)
+
+bool persistent_supported(int N, int B, int n_cus) {
+    if (N % 64 != 0 || N > 1024) return false;
+    const int NG = (B + 15) / 16;
+    int fb = 0, bb = 0;
+    switch (N / 64) {
+#define X(k) case k: fb = blocks_per_cu(k_fwd_persistent<k, false>, 256); break;
+        FWD_CASES(X)
+#undef X
+        default: return false;
+    }
+    switch (N / 32) {
+#define X(k) case k: bb = blocks_per_cu(k_bwd_persistent<k>, 512); break;
+        BWD_CASES(X)
+#undef X
+        default: return false;
+    }
+    // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md, residency): keep a margin
+    if (fb > 1) fb -= 1;
+    if (bb > 1) bb -= 1;
+    if (fb > 8) fb = 8;
+    return (size_t)(N / 4) * NG <= (size_t)fb * n_cus && (size_t)(N / 16) * NG <= (size_t)bb * n_cus;
+}
+
+void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
+                    const int32_t *xi, unsigned *cnt, unsigned *abortp, int N, int S, int B, bool fast, hipStream_t st) {
+    const dim3 grid(N / 4, (B + 15) / 16), block(256);
+    switch (N / 64) {
+#define X(k)                                                                                                          \
+    case k:                                                                                                           \
+        if (fast) hipLaunchKernelGGL((k_fwd_persistent<k, true>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, S, B); \
+        else hipLaunchKernelGGL((k_fwd_persistent<k, false>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, S, B);    \
+        break;
+        FWD_CASES(X)
+#undef X
+    }
+}
+
+void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, unsigned *cnt,
+                    unsigned *abortp, int N, int S, int B, hipStream_t st) {
+    const dim3 grid(N / 16, (B + 15) / 16), block(512);
+    switch (N / 32) {
+#define X(k)                                                                                              \
+    case k:                                                                                               \
+        hipLaunchKernelGGL((k_bwd_persistent<k>), grid, block, 0, st, Ubwd, DG, DHy, G, C, cnt, abortp, S, B); \
+        break;
+        BWD_CASES(X)
+#undef X
+    }
+}
+
+} // namespace lstmk

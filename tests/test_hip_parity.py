@@ -50,6 +50,23 @@ def _run_hip(lstm_hip, N, S, B, P, xi, ti, h0, c0, lr=None, flags=0):
     return out
 
 
+@pytest.mark.parametrize("N,S,B,empty", [(64, 6, 20, ((1, 0), (2, 19))), (128, 12, 33, ())])
+def test_window_matches_oracle_step_engine(N, S, B, empty, oracle32):
+    """Same check with LSTM_HIP_STEP_KERNELS: the one-launch-per-timestep engine (also the fallback
+    when the persistent grid would not be co-resident)."""
+    import lstm_hip
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=N + S + B, empty=empty)
+    fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
+    dref = oracle32.backward(N, 256, S, B, P, xi, ti, fw)
+    got = _run_hip(lstm_hip, N, S, B, P, xi, ti, h0, c0, flags=lstm_hip.STEP_KERNELS)
+    for t in range(1, S):
+        for name in ("h", "c", "g", "probs"):
+            assert gu.max_rel(got[name][t - 1], fw[name][t]) <= ACT_TOL, (name, t)
+    assert abs(got["loss"] - fw["loss_bits"]) <= LOSS_TOL * (S - 1)
+    rep = gu.grads_report(got["grads"], dref, N)
+    assert max(rep.values()) <= GRAD_TOL, rep
+
+
 @pytest.mark.parametrize("N,S,B,empty", CASES)
 def test_window_matches_oracle(N, S, B, empty, oracle32):
     import lstm_hip
@@ -129,3 +146,134 @@ def test_sampler_matches_oracle(oracle32):
     assert (got == want).mean() >= 0.99
     if (got == want).all():
         assert gu.max_rel(hg, hw) <= 1e-4
+
+
+def _synthetic_text(n, seed=3):
+    rs = np.random.RandomState(seed)
+    return rs.choice(np.arange(32, 127), size=n, p=None).astype(np.uint8)
+
+
+@pytest.mark.parametrize("N,S,B,windows", [(32, 6, 4, 40), (64, 10, 20, 25)])
+def test_device_resident_loop_follows_the_oracle_trainer(N, S, B, windows, oracle32):
+    """lstm_hip_train_windows (slide + forward + loss + BPTT + Adagrad on the device) against the
+    oracle's restatement of the reference loop (OV/lstm_eigen_opt/lstm.cc:186-318), same seed.
+    Starts with an EMPTY window (all-zero x/target columns) and a text short enough that the cursors
+    wrap (pos >= len -> S), so both edge paths are exercised.
+
+    Lock-step form (the reference's own CPU-vs-GPU check pattern, OV/lstm_eigen_CUDA/lstm.cu:501-520):
+    before every window the device's parameters, Adagrad memory and carry are re-synchronised to the
+    oracle's, so each window is compared from identical state: loss |d| <= 2e-5*(S-1), parameters
+    after the step |d| <= 2e-4*lr where the gradient is above noise.  The window indices and cursors
+    live on the device the whole time and must match bit for bit."""
+    import lstm_hip
+    text = _synthetic_text(S + 24)
+    lr = 0.1
+    tr = oracle32.trainer(text, N, S, B, lr=lr, seed=1)
+    tr.epoch_reset()
+    L = lstm_hip.Lstm(N, S, B)
+    L.set_text(text)
+    pos0 = lstm_hip.initial_cursors(len(text), S, B)
+    L.set_cursors(pos0)
+    L.reset_window()
+    for w in range(windows):
+        L.set_params(tr.params.copy())
+        L.set_params(tr.mem.copy(), lstm_hip.P_MEM)
+        L.set_state(1, tr.h[1], tr.c[1])  # column 1 becomes the carry after the slide
+        got = L.train_windows(1, lr)[0]
+        want = tr.window()
+        assert abs(got - want) <= LOSS_TOL * (S - 1), (w, got, want)
+        xi, ti = L.get_window()
+        assert np.array_equal(xi, tr.xi) and np.array_equal(ti, tr.ti), w          # bit-exact index work
+        h1, c1 = L.get_state(1)
+        assert gu.max_rel(h1, tr.h[1]) <= ACT_TOL and gu.max_rel(c1, tr.c[1]) <= ACT_TOL
+        d = tr.grads
+        mask = np.abs(d) > 1e-3 * np.abs(d).max()
+        assert np.abs(L.get_params()[mask] - tr.params[mask]).max() <= 2e-4 * lr + 1e-6, w
+    want_pos = np.array([_wrap(int(p), windows, len(text), S) for p in pos0])
+    assert np.array_equal(L.get_cursors().astype(np.int64), want_pos)
+    L.close()
+
+
+def test_free_running_trajectory_stays_near_the_oracle(oracle32):
+    """Same loop without re-synchronisation.  Trajectories separate (Adagrad's first steps are
+    +-lr*sign(d), so a rounding-level sign flip of a near-zero gradient moves a weight by 2*lr;
+    SURVEY 7 hard part 2): tight for the first windows, loose afterwards, averages agree."""
+    import lstm_hip
+    N, S, B, windows, lr = 64, 10, 20, 60, 0.1
+    text = _synthetic_text(4000, seed=5)
+    tr = oracle32.trainer(text, N, S, B, lr=lr, seed=1)
+    tr.epoch_reset()
+    L = lstm_hip.Lstm(N, S, B)
+    L.set_params(tr.params.copy())
+    L.set_state(1, tr.h[1], tr.c[1])
+    L.set_text(text)
+    L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
+    L.reset_window()
+    got = L.train_windows(windows, lr)
+    want = np.array([tr.window() for _ in range(windows)])
+    L.close()
+    d = np.abs(got - want)
+    assert d[:3].max() <= 1e-3, d[:3]
+    per_char = d / (S - 1)
+    assert per_char.max() <= 0.25, per_char.max()                    # bits/char, any single window
+    assert abs(got[-20:].mean() - want[-20:].mean()) / (S - 1) <= 0.05  # bits/char, late average
+
+
+def _wrap(p, n, length, S):
+    for _ in range(n):
+        p += 1
+        if p >= length:
+            p = S
+    return p
+
+
+def test_split_batch_gradients_sum_to_full_batch():
+    """Data-parallel decomposition without RCCL: two handles each own half the streams; their
+    gradient blocks summed equal the full-batch gradients (weight gradients are sums over columns,
+    OV/lstm_eigen_opt/lstm.cc:271,297-299), and the losses add (each divided by the GLOBAL batch)."""
+    import lstm_hip
+    N, S, B = 64, 8, 32
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=77)
+
+    def run(cols):
+        L = lstm_hip.Lstm(N, S, len(cols))
+        L.set_params(P)
+        L.set_state(0, h0[cols], c0[cols])
+        L.set_window(xi[:, cols], ti[:, cols])
+        L.set_global_batch(B)
+        L.forward()
+        loss = L.loss()
+        L.backward()
+        g = L.get_grads()
+        L.close()
+        return loss, g
+
+    lf, gf = run(np.arange(B))
+    l0, g0 = run(np.arange(0, B // 2))
+    l1, g1 = run(np.arange(B // 2, B))
+    assert abs((l0 + l1) - lf) <= 1e-4
+    rep = gu.grads_report(g0 + g1, gf, N)
+    assert max(rep.values()) <= 2e-5, rep
+
+
+def test_headline_shape_one_window_vs_oracle():
+    """BASELINE configs[2] (hidden 512, window 100, batch 64): one full window against the oracle
+    (OpenMP build, same arithmetic as the serial one), plus size-independent properties:
+    probabilities sum to 1, db equals the sum of dW over input bytes (x is one-hot), dby sums to ~0."""
+    import lstm_hip
+    from oracle_lib import Oracle
+    N, S, B = 512, 100, 64
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=2024, scale=0.02)
+    orc = Oracle("f32_omp")
+    fw = orc.forward(N, 256, S, B, P, xi, ti, h0, c0)
+    dref = orc.backward(N, 256, S, B, P, xi, ti, fw)
+    got = _run_hip(lstm_hip, N, S, B, P, xi, ti, h0, c0)
+    assert gu.max_rel(got["h"][-1], fw["h"][S - 1]) <= ACT_TOL
+    assert gu.max_rel(got["c"][S // 2], fw["c"][S // 2 + 1]) <= ACT_TOL
+    assert abs(got["loss"] - fw["loss_bits"]) <= LOSS_TOL * (S - 1)
+    rep = gu.grads_report(got["grads"], dref, N)
+    assert max(rep.values()) <= GRAD_TOL, rep
+    g = split_params(got["grads"], N)
+    np.testing.assert_allclose(np.sum(got["probs"][-1], axis=1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(g["W"].sum(axis=1), g["b"][:, 0], rtol=1e-3, atol=1e-3 * np.abs(g["b"]).max())
+    assert abs(g["by"].sum()) <= 1e-2
