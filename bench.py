@@ -97,6 +97,7 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    import dp
     import lstm_hip
 
     N, S, B, lr = args.hidden, args.seq, args.batch, args.lr
@@ -112,7 +113,7 @@ def main():
     srng = lstm_hip.MT19937Normal(1000 + rank)
     L.set_state(1, srng.randn(N, B, 0.0, 0.1), srng.randn(N, B, 0.0, 0.1))  # becomes column 0 after the first slide
     L.set_text(text)
-    L.set_cursors(lstm_hip.initial_cursors(len(text), S, B, stream0=rank * B, streams_total=world * B))
+    L.set_cursors(dp.cursors(len(text), S, rank, world, world * B))  # rank r owns streams [r*B, (r+1)*B)
     L.set_global_batch(world * B)
     if world > 1:
         ids = [lstm_hip.comm_unique_id() if rank == 0 else None]

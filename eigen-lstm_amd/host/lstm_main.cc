@@ -1,0 +1,376 @@
+// lstm_main.cc -- the C++ host program: the reference's main() (R/lstm.cc:50-361, batched per
+// OV/lstm_eigen_opt/lstm.cc:47-413) with its compile-time constants turned into a command line and
+// the loop body handed to the MI355X through the C ABI (include/lstm_hip.h).  No HIP, no torch here.
+//
+//   lstm <text file> <hidden> <seq> <batch> <lr> [options]        (the reference's knobs, R/lstm.cc:53-63)
+//   lstm --data F --hidden N --seq S --batch B --lr LR [--epochs E] [--seed K] [--gpus G]
+//        [--windows W] [--sample C] [--lr-warmup-windows X] [--save PREFIX] [--load PREFIX]
+//        [--eval-file F] [--fast-math] [--step-kernels] [--quiet]
+//
+// stdout follows the reference: "Read N bytes (file)" (R/lstm.cc:398), the carriage-return progress
+// line (OV/lstm_eigen_opt/lstm.cc:320-331), the epoch summary (R/lstm.cc:284-291: GFLOP uses 2^30,
+// loss divided by S*length) and the "Generated text |...|" block (R/lstm.cc:352-356).
+//
+// --gpus G forks one process per GPU before anything touches HIP; batch streams are sharded
+// rank-major, the RCCL unique id travels over a pipe, and every window ends with one SUM
+// all-reduce of the flat gradient block inside the library.
+// --lr-warmup-windows X applies lr = 0 for the first X windows (the reference's GPU driver uses
+// X = 50*S, OV/lstm_eigen_class_CUDA/lstm.cc:364-367; 0 = the root file's behaviour).
+#include "../../include/lstm_hip.h"
+#include "rng.h"
+
+#include <sys/time.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Options {
+    std::string data = "alice29.txt"; // R/lstm.cc:63
+    int N = 64, S = 3, B = 1;         // R/lstm.cc:53-57, OV/lstm_eigen_opt/lstm.cc:56
+    double lr = 1e-1;                 // R/lstm.cc:59
+    long epochs = 1000;               // R/lstm.cc:60
+    uint32_t seed = 1;
+    int gpus = 1;
+    long windows = -1;        // cap on windows per epoch (-1: length - S, R/lstm.cc:151)
+    int sample = 1000;        // R/lstm.cc:295
+    long lr_warmup = 0;
+    std::string save, load, eval_file;
+    unsigned flags = 0;
+    bool quiet = false;
+};
+
+[[noreturn]] void die(const std::string &m) {
+    fprintf(stderr, "lstm: %s\n", m.c_str());
+    exit(2);
+}
+#define CK(call)                                                          \
+    do {                                                                  \
+        int rc_ = (call);                                                 \
+        if (rc_ != 0) die(std::string(#call) + ": " + lstm_hip_last_error()); \
+    } while (0)
+
+double now() { // Timer, R/timer.h:21-41
+    timeval tv;
+    gettimeofday(&tv, nullptr);
+    return tv.tv_sec + 1e-6 * tv.tv_usec;
+}
+
+// rawread, R/lstm.cc:382-420
+std::vector<uint8_t> rawread(const std::string &filename) {
+    std::vector<uint8_t> v;
+    if (FILE *fp = fopen(filename.c_str(), "rb")) {
+        char buf[1 << 16];
+        while (size_t len = fread(buf, 1, sizeof(buf), fp)) v.insert(v.end(), buf, buf + len);
+        fclose(fp);
+        if (!v.empty()) printf("Read %zu bytes (%s)\n", v.size(), filename.c_str());
+        else printf("Empty file! (%s)\n", filename.c_str());
+    } else {
+        printf("fopen error: (%s)\n", filename.c_str());
+    }
+    return v;
+}
+
+// count_flops, OV/lstm_eigen_class_CUDA/lstm.cc:722-747 (the model behind the reference's GFlOP/s)
+double count_flops(double M, double N, double S, double B) {
+    return (S - 1) * ((N * M * B * 2) + (N * 4 * N * B) + (N * 4 * B * 2) + (5 * N * 4 * B) + (6 * N * B) + (M * N * B * 2) +
+                      (8 * N * B) + (N * B) + (M * B * N * 3) + (N * B * 6) + (N * M * B * 4) + (N * B * 8) +
+                      (N * 4 * B * M * 3) + (N * 4 * B * N * 3) + (N * 4 * B) + (N * 4 * N * B * 2) + (N * B)) +
+           8 * (M * N + M + N * 4 * N + N * 4 * M + N * 4);
+}
+
+// Parameters::save_to_disk / load_from_disk, OV/lstm_eigen_class_CUDA/lstm.h:83-101, io.h:16-74:
+// five text files <prefix>_{W,U,Why,b,by}.txt, one matrix row per line, 6 significant digits.
+struct Block {
+    const char *name;
+    size_t rows, cols, off;
+};
+std::vector<Block> blocks(int N, int M) {
+    size_t o = 0;
+    std::vector<Block> b;
+    auto add = [&](const char *n, size_t r, size_t c) {
+        b.push_back({n, r, c, o});
+        o += r * c;
+    };
+    add("W", 4 * (size_t)N, M);
+    add("U", 4 * (size_t)N, N);
+    add("b", 4 * (size_t)N, 1);
+    add("Why", M, N);
+    add("by", M, 1);
+    return b;
+}
+void save_params(const std::string &prefix, const std::vector<float> &P, int N, int M) {
+    for (const Block &b : blocks(N, M)) {
+        std::ofstream f(prefix + "_" + b.name + ".txt");
+        if (!f) die("cannot write " + prefix + "_" + b.name + ".txt");
+        f.precision(6);
+        for (size_t r = 0; r < b.rows; r++) {
+            for (size_t c = 0; c < b.cols; c++) f << (c ? " " : "") << P[b.off + c * b.rows + r];
+            f << "\n";
+        }
+    }
+}
+bool load_params(const std::string &prefix, std::vector<float> &P, int N, int M) {
+    for (const Block &b : blocks(N, M)) {
+        std::ifstream f(prefix + "_" + b.name + ".txt");
+        if (!f) return false;
+        std::string line;
+        size_t r = 0;
+        while (std::getline(f, line)) {
+            std::istringstream ss(line);
+            double v;
+            size_t c = 0;
+            while (ss >> v) {
+                if (r < b.rows && c < b.cols) P[b.off + c * b.rows + r] = (float)v;
+                c++;
+            }
+            if (c == 0) continue;
+            if (c != b.cols) die(prefix + "_" + b.name + ".txt: row " + std::to_string(r) + " has " + std::to_string(c) + " columns");
+            r++;
+        }
+        if (r != b.rows) die(prefix + "_" + b.name + ".txt: " + std::to_string(r) + " rows, expected " + std::to_string(b.rows));
+    }
+    return true;
+}
+
+Options parse(int argc, char **argv) {
+    Options o;
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto val = [&]() -> std::string {
+            if (i + 1 >= argc) die("missing value for " + a);
+            return argv[++i];
+        };
+        if (a == "--data") o.data = val();
+        else if (a == "--hidden") o.N = atoi(val().c_str());
+        else if (a == "--seq") o.S = atoi(val().c_str());
+        else if (a == "--batch") o.B = atoi(val().c_str());
+        else if (a == "--lr") o.lr = atof(val().c_str());
+        else if (a == "--epochs") o.epochs = atol(val().c_str());
+        else if (a == "--seed") o.seed = (uint32_t)strtoul(val().c_str(), nullptr, 10);
+        else if (a == "--gpus") o.gpus = atoi(val().c_str());
+        else if (a == "--windows") o.windows = atol(val().c_str());
+        else if (a == "--sample") o.sample = atoi(val().c_str());
+        else if (a == "--lr-warmup-windows") o.lr_warmup = atol(val().c_str());
+        else if (a == "--save") o.save = val();
+        else if (a == "--load") o.load = val();
+        else if (a == "--eval-file") o.eval_file = val();
+        else if (a == "--fast-math") o.flags |= LSTM_HIP_FAST_MATH;
+        else if (a == "--step-kernels") o.flags |= LSTM_HIP_STEP_KERNELS;
+        else if (a == "--quiet") o.quiet = true;
+        else if (a == "-h" || a == "--help") {
+            printf("usage: lstm <text file> <hidden> <seq> <batch> <lr> [--epochs E --seed K --gpus G --windows W --sample C\n"
+                   "            --lr-warmup-windows X --save PREFIX --load PREFIX --eval-file F --fast-math --step-kernels --quiet]\n");
+            exit(0);
+        } else if (a.rfind("--", 0) == 0) die("unknown option " + a);
+        else pos.push_back(a);
+    }
+    if (pos.size() > 0) o.data = pos[0];
+    if (pos.size() > 1) o.N = atoi(pos[1].c_str());
+    if (pos.size() > 2) o.S = atoi(pos[2].c_str());
+    if (pos.size() > 3) o.B = atoi(pos[3].c_str());
+    if (pos.size() > 4) o.lr = atof(pos[4].c_str());
+    if (o.gpus < 1 || o.B % o.gpus != 0) die("--batch must be a multiple of --gpus");
+    return o;
+}
+
+// one rank = one GPU.  `up`/`down` are pipes to/from the parent when gpus > 1.
+int run_rank(const Options &o, int rank, int up, int down) {
+    const int M = LSTM_HIP_VOCAB, N = o.N, S = o.S, Bl = o.B / o.gpus;
+    const bool lead = rank == 0;
+    std::vector<uint8_t> data = rawread(o.data);
+    if (data.size() <= (size_t)S + 1) die("text too short");
+    const size_t length = data.size();
+
+    lstm_hip_config cfg{N, M, S, Bl, rank, o.flags};
+    lstm_hip_t *h = nullptr;
+    CK(lstm_hip_create(&cfg, &h));
+    if (o.gpus > 1) {
+        uint8_t id[LSTM_HIP_UNIQUE_ID_BYTES];
+        if (lead) {
+            CK(lstm_hip_comm_unique_id(id));
+            if (write(up, id, sizeof(id)) != (ssize_t)sizeof(id)) die("pipe write");
+        }
+        if (read(down, id, sizeof(id)) != (ssize_t)sizeof(id)) die("pipe read");
+        CK(lstm_hip_comm_init(h, id, o.gpus, rank));
+        CK(lstm_hip_set_global_batch(h, o.B));
+    }
+
+    // init: W, U, Why ~ N(0, 0.01) in that order, b = by = 0 (R/lstm.cc:113-119); same on all ranks
+    const size_t np = lstm_hip_param_count(N, M);
+    std::vector<float> P(np, 0.0f);
+    SeededRng rng(o.seed);
+    {
+        auto bl = blocks(N, M);
+        rng.randn(P.data() + bl[0].off, 4 * N, M, 0.0, 0.01);
+        rng.randn(P.data() + bl[1].off, 4 * N, N, 0.0, 0.01);
+        rng.randn(P.data() + bl[3].off, M, N, 0.0, 0.01);
+    }
+    if (!o.load.empty()) {
+        if (load_params(o.load, P, N, M)) {
+            if (lead) printf("Loaded parameters from %s_{W,U,Why,b,by}.txt\n", o.load.c_str());
+        } else if (lead) printf("fopen error: (%s_W.txt) -- keeping the random initialisation\n", o.load.c_str());
+    }
+    CK(lstm_hip_set_params(h, 0, P.data()));
+    CK(lstm_hip_set_text(h, data.data(), length));
+
+    // cursors: deterministic stand-in for rand() % (length - S) + S (OV/lstm_eigen_opt/lstm.cc:140-144)
+    std::vector<uint64_t> pos(Bl);
+    for (int b = 0; b < Bl; b++) pos[b] = (uint64_t)S + ((uint64_t)(rank * Bl + b) * (length - S)) / (uint64_t)o.B;
+    CK(lstm_hip_set_cursors(h, pos.data()));
+    CK(lstm_hip_reset_window(h));
+
+    const double flops_per_iteration = count_flops(M, N, S, o.B);
+    const long windows_per_epoch = (o.windows > 0) ? o.windows : (long)(length - S);
+    long done_windows = 0;
+    std::vector<float> hs((size_t)N * o.B), cs((size_t)N * o.B);
+    std::vector<double> losses;
+
+    for (long e = 0; e < o.epochs; e++) {
+        // epoch start: h[t], c[t] ~ N(0, 0.1) for every t (OV/lstm_eigen_opt/lstm.cc:176-181); drawn for
+        // the GLOBAL batch so every rank consumes the same stream, each keeps its own columns
+        for (int t = 0; t < S; t++) {
+            rng.randn(hs.data(), N, o.B, 0.0, 0.1);
+            rng.randn(cs.data(), N, o.B, 0.0, 0.1);
+            CK(lstm_hip_set_state(h, t, hs.data() + (size_t)rank * Bl * N, cs.data() + (size_t)rank * Bl * N));
+        }
+        double epoch_loss = 0.0;
+        const double t0 = now();
+        double tf = t0;
+        for (long i = 0; i < windows_per_epoch;) {
+            long chunk = std::min<long>(100, windows_per_epoch - i); // progress every 100 iterations (opt:320)
+            double lr = o.lr;
+            if (done_windows < o.lr_warmup) {
+                lr = 0.0;
+                chunk = std::min<long>(chunk, o.lr_warmup - done_windows);
+            }
+            losses.resize(chunk);
+            CK(lstm_hip_train_windows(h, chunk, lr, losses.data(), nullptr));
+            for (double v : losses)
+                if (!std::isnan(v)) epoch_loss += v; // NaN guard as OV/lstm_eigen_class_CUDA/lstm.cc:325-326
+            i += chunk;
+            done_windows += chunk;
+            if (lead && !o.quiet) {
+                const double t1 = now();
+                printf("%9.2f%% %9.2f GFlOP/s\r", 100.0 * (double)(i + S) / (double)length,
+                       (chunk * flops_per_iteration / std::pow(2.0, 30)) / (t1 - tf));
+                fflush(stdout);
+                tf = t1;
+            }
+        }
+        const double epoch_time = now() - t0;
+        if (o.gpus > 1) { // sum the ranks' partial losses (each already divided by the global batch)
+            if (write(up, &epoch_loss, sizeof(double)) != (ssize_t)sizeof(double)) die("pipe write");
+            if (read(down, &epoch_loss, sizeof(double)) != (ssize_t)sizeof(double)) die("pipe read");
+        }
+        if (lead) {
+            const double chars = (double)(S - 1) * o.B * windows_per_epoch;
+            printf("\n====================================================================================\n");
+            printf("Epoch %ld/%ld, t = %.3f s, est GFLOP/s = %.3f, avg loss = %.3f bits/char\n", e + 1, o.epochs, epoch_time,
+                   (flops_per_iteration * windows_per_epoch / std::pow(2.0, 30)) / epoch_time,
+                   epoch_loss / ((double)S * (double)(windows_per_epoch + S))); // R/lstm.cc:290: loss/(S*length)
+            printf("chars/s through fwd+BPTT = %.1f (%ld windows, %d GPU%s)\n", chars / epoch_time, windows_per_epoch, o.gpus,
+                   o.gpus > 1 ? "s" : "");
+            if (!o.eval_file.empty()) {
+                std::vector<uint8_t> ev = rawread(o.eval_file);
+                double bits = 0.0;
+                if (ev.size() > 1) {
+                    CK(lstm_hip_eval_bits(h, ev.data(), ev.size(), &bits));
+                    printf("Test error: %.5f bits/char (%s)\n", bits, o.eval_file.c_str());
+                }
+            }
+            if (o.sample > 0) { // R/lstm.cc:293-356
+                std::vector<float> h0(N), c0(N);
+                rng.randn(h0.data(), N, 1, 0.0, 0.1);
+                rng.randn(c0.data(), N, 1, 0.0, 0.1);
+                std::vector<double> u(o.sample);
+                for (double &x : u) x = rng.uniform();
+                std::vector<uint8_t> text(o.sample);
+                CK(lstm_hip_sample(h, h0.data(), c0.data(), u.data(), o.sample, text.data()));
+                printf("\n\n************ Generated text |");
+                fwrite(text.data(), 1, text.size(), stdout);
+                printf("| Generated text END ************\n");
+            } else { // keep the RNG stream aligned across ranks
+            }
+            if (!o.save.empty()) {
+                CK(lstm_hip_get_params(h, 0, P.data()));
+                save_params(o.save, P, N, M);
+                printf("Saved parameters to %s_{W,U,Why,b,by}.txt\n", o.save.c_str());
+            }
+            fflush(stdout);
+        }
+        if (!lead && o.sample > 0) { // non-lead ranks consume the same draws so later epochs stay in step
+            std::vector<float> tmp(N);
+            rng.randn(tmp.data(), N, 1, 0.0, 0.1);
+            rng.randn(tmp.data(), N, 1, 0.0, 0.1);
+            for (int k = 0; k < o.sample; k++) (void)rng.uniform();
+        }
+    }
+    CK(lstm_hip_destroy(h));
+    return 0;
+}
+
+} // namespace
+
+int main(int argc, char **argv) {
+    Options o = parse(argc, argv);
+    if (o.gpus == 1) return run_rank(o, 0, -1, -1);
+
+    // one process per GPU, forked before any HIP call
+    std::vector<int> up_r(o.gpus), down_w(o.gpus);
+    std::vector<pid_t> kids(o.gpus);
+    for (int r = 0; r < o.gpus; r++) {
+        int up[2], down[2];
+        if (pipe(up) != 0 || pipe(down) != 0) die("pipe");
+        pid_t pid = fork();
+        if (pid < 0) die("fork");
+        if (pid == 0) {
+            close(up[0]);
+            close(down[1]);
+            if (r != 0) { // only rank 0 talks on stdout
+                if (!freopen("/dev/null", "w", stdout)) _exit(3);
+            }
+            _exit(run_rank(o, r, up[1], down[0]));
+        }
+        close(up[1]);
+        close(down[0]);
+        up_r[r] = up[0];
+        down_w[r] = down[1];
+        kids[r] = pid;
+    }
+    // relay the unique id, then one loss sum per epoch
+    uint8_t id[LSTM_HIP_UNIQUE_ID_BYTES];
+    if (read(up_r[0], id, sizeof(id)) != (ssize_t)sizeof(id)) die("rank 0 did not produce a unique id");
+    for (int r = 0; r < o.gpus; r++)
+        if (write(down_w[r], id, sizeof(id)) != (ssize_t)sizeof(id)) die("relay");
+    for (long e = 0; e < o.epochs; e++) {
+        double sum = 0.0;
+        bool ok = true;
+        for (int r = 0; r < o.gpus; r++) {
+            double v = 0.0;
+            if (read(up_r[r], &v, sizeof(v)) != (ssize_t)sizeof(v)) ok = false;
+            sum += v;
+        }
+        if (!ok) break;
+        for (int r = 0; r < o.gpus; r++)
+            if (write(down_w[r], &sum, sizeof(sum)) != (ssize_t)sizeof(sum)) ok = false;
+        if (!ok) break;
+    }
+    int rc = 0;
+    for (int r = 0; r < o.gpus; r++) {
+        int st = 0;
+        waitpid(kids[r], &st, 0);
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+    }
+    return rc;
+}

@@ -1,0 +1,61 @@
+"""-m gpu: the C++ host program (eigen-lstm_amd/lstm) end to end: command line in, the reference's
+stdout report out, checked against the oracle's restatement of the same loop with the same seed."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LSTM = os.path.join(ROOT, "eigen-lstm_amd", "lstm")
+
+
+def _text(n=3000, seed=11):
+    rs = np.random.RandomState(seed)
+    words = [bytes(rs.randint(97, 123, size=rs.randint(2, 8)).astype(np.uint8)) for _ in range(60)]
+    out = b" ".join(words[i] for i in rs.randint(0, 60, size=n))
+    return np.frombuffer(out[:n], dtype=np.uint8).copy()
+
+
+def test_cli_epoch_report_matches_oracle(tmp_path, oracle32):
+    N, S, B, lr, windows = 32, 8, 4, 0.1, 60
+    text = _text()
+    f = tmp_path / "corpus.txt"
+    text.tofile(f)
+    out = subprocess.run([LSTM, str(f), str(N), str(S), str(B), str(lr), "--epochs", "1", "--windows", str(windows),
+                          "--seed", "1", "--sample", "50", "--save", str(tmp_path / "ck")],
+                         capture_output=True, text=True, errors="replace", timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert f"Read {len(text)} bytes ({f})" in out.stdout                        # R/lstm.cc:398
+    m = re.search(r"Epoch 1/1, t = ([\d.]+) s, est GFLOP/s = ([\d.]+), avg loss = ([\d.]+) bits/char", out.stdout)
+    assert m, out.stdout                                                          # R/lstm.cc:284-291
+    assert "************ Generated text |" in out.stdout and "| Generated text END ************" in out.stdout
+    tr = oracle32.trainer(text, N, S, B, lr=lr, seed=1)
+    tr.epoch_reset()
+    epoch_loss = sum(tr.window() for _ in range(windows))
+    want = epoch_loss / (S * (windows + S))
+    assert abs(float(m.group(3)) - want) <= 2e-3, (m.group(3), want)
+    # checkpoint in the reference's text format (OV/lstm_eigen_class_CUDA/lstm.h:83-101): 5 files, row per line
+    W = np.loadtxt(tmp_path / "ck_W.txt", ndmin=2)
+    assert W.shape == (4 * N, 256)
+    by = np.loadtxt(tmp_path / "ck_by.txt", ndmin=2)
+    assert by.shape == (256, 1)
+    # ... and it loads back: evaluating from the checkpoint reproduces the evaluator's number
+    out2 = subprocess.run([LSTM, str(f), str(N), str(S), str(B), "0.0", "--epochs", "1", "--windows", "1", "--load",
+                           str(tmp_path / "ck"), "--eval-file", str(f), "--sample", "0"],
+                          capture_output=True, text=True, errors="replace", timeout=120)
+    assert out2.returncode == 0, out2.stderr
+    m2 = re.search(r"Test error: ([\d.]+) bits/char", out2.stdout)
+    assert m2, out2.stdout
+    from oracle_lib import Oracle
+    P = np.concatenate([np.loadtxt(tmp_path / f"ck_{k}.txt", ndmin=2).astype(np.float32).flatten(order="F")
+                        for k in ("W", "U", "b", "Why", "by")])
+    assert abs(float(m2.group(1)) - oracle32.eval_bits(N, 256, P, text)) <= 1e-3
+
+
+def test_cli_rejects_bad_arguments():
+    out = subprocess.run([LSTM, "/nonexistent.txt", "24", "5", "2", "0.1"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0
+    assert "fopen error" in out.stdout or "too short" in out.stderr           # R/lstm.cc:416 wording
