@@ -36,14 +36,20 @@ void bwd_step(const float4 *Ubwd, const float *DGnext /*null at t=S-1*/, const f
 
 // ---- default engine: each recurrence of a window as ONE persistent launch (persistent.hip) ----
 // Weights stay in VGPRs; steps are chained by sc1 stores + sharded device-scope counters.
-// `cnt` must hold persistent_counter_bytes() zeroed bytes (separate regions for fwd and bwd);
+// `cnt` must hold persistent_counter_bytes() bytes (separate regions for fwd and bwd), zeroed once;
+// `epoch` = 1, 2, ... counts the launches that used that region (counters are cumulative);
 // `abortp` is one zeroed word that a timed-out spin sets.
 size_t persistent_counter_bytes(int S, int B);
 bool persistent_supported(int N, int B, int n_cus);
 void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
-                    const int32_t *xi, unsigned *cnt, unsigned *abortp, int N, int S, int B, bool fast, hipStream_t st);
+                    const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B, bool fast,
+                    hipStream_t st, unsigned long long *stamps = nullptr);
+// granule hand-off form (LSTM_HIP_GRANULE_HANDOFF): Hg holds S*B*N 8-byte {value, tag} granules; epoch_base = S * window serial
+void fwd_persistent_granules(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
+                              unsigned long long *Hg, const int32_t *xi, unsigned *abortp, unsigned epoch_base, int N,
+                              int S, int B, bool fast, hipStream_t st);
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, unsigned *cnt,
-                    unsigned *abortp, int N, int S, int B, hipStream_t st);
+                    unsigned *abortp, unsigned epoch, int N, int S, int B, hipStream_t st);
 
 // ---- time-batched dense products (fp32 MFMA 32x32x2, LDS tiled) ------------------------------
 // C[M x Nn] = op(A)[M x K] * op(B)[K x Nn], column-major; TA: A is stored K x M; TB: B is stored Nn x K.
@@ -58,20 +64,24 @@ int gemm_pick_splits(int M, int Nn, int K);
 // colloss[col] = -log2 p[target] (0 for an empty target); dby_part[wave][256] partial row sums of dY.
 void softmax_loss_dy(float *Y, float *P, const float *by, const int32_t *ti, float *colloss, float *dby_part, int T,
                      int *n_parts_out, hipStream_t st);
-void dby_finish(const float *dby_part, int n_parts, float *dby, hipStream_t st);
-// window loss as the reference sums it: for each t a float sum over b, / B_global, accumulated in double
-void loss_reduce(const float *colloss, int steps, int B, int B_global, double *out, hipStream_t st);
+// window loss as the reference sums it: for each t a float sum over b, / B_global, accumulated in double;
+// when dby != null a second workgroup folds the per-wave partials into dby = rowsum(dY) (R/lstm.cc:227)
+void loss_reduce(const float *colloss, int steps, int B, int B_global, double *out, const float *dby_part, int n_parts,
+                 float *dby, hipStream_t st);
 
 // ---- dW = DG * X^T and db = rowsum(DG)                                        (R/lstm.cc:251-252)
-// X is one-hot, so dW[:,v] is the sum of the DG columns whose input byte is v: each workgroup owns
-// DW_ROWS gate rows, streams over the T columns and accumulates into a [257][rows][copies] LDS
-// table with ds_add_f32 (bucket 256 = empty input column).  Every LDS word is touched by ONE thread
-// in column order, so the result is deterministic.  db[r] = sum over the 257 buckets.
+// X is one-hot, so dW[:,v] is the sum of the DG columns whose input byte is v (bucket 256 = empty
+// input column); db[r] = sum over the 257 buckets.  Stable counting sort of the column ids, ordered
+// chunk sums, ordered folds: deterministic.  `scratch` must hold dW_scratch_bytes(T, G4).
+constexpr int DW_CHUNK = 32;
+size_t dW_scratch_bytes(int T, int G4);
 void dW_db(const float *DG /*[T][G4]*/, const int32_t *xi /*[T]*/, int T, int G4, float *dW /*[256][G4]*/, float *db,
-           hipStream_t st);
+           void *scratch, hipStream_t st);
 
 // ---- Adagrad over the flat block (R/lstm.cc:261-272; eps added in double, :25,46-48)
-void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, hipStream_t st);
+// When Ufwd/Ubwd are given, the U block also refreshes both MFMA fragment images (fused pack_U).
+void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
+             hipStream_t st);
 
 // ---- window builder on the device (OV/lstm_eigen_opt/lstm.cc:190-213): x/target rings + flat copies,
 //      cursor advance, and the h/c carry (column 1 -> column 0).  Single workgroup.

@@ -284,16 +284,17 @@ void bwd_step(const float4 *Ubwd, const float *DGnext, const float *DHy_t, const
 // row index) so the accumulator holds C^T fragments: lanes then run along m, which is contiguous in
 // column-major C, and the epilogue stores are coalesced.
 // ------------------------------------------------------------------------------------------------
-constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = 132;
+constexpr int GBM = 128, GBK = 16, GLD = 132; // BN = 64*NI (NI = 1 or 2 n-fragments of 32 per wave)
 
-template <bool TRANS> // TRANS=false: source is [rows contiguous] x K ; TRANS=true: source is K-contiguous
+// ROWS = 128 or 64 tile rows (m or n); a 64-row tile needs one float4 per thread (q = 0 only)
+template <bool TRANS, int ROWS> // TRANS=false: source is [rows contiguous] x K ; TRANS=true: source is K-contiguous
 __device__ __forceinline__ void gemm_load(const float *__restrict__ src, int ld, int r0, int rmax, int k0, int kend,
                                           int tid, float4 (&reg)[2]) {
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < ROWS / 64; q++) {
         float4 v = {0.f, 0.f, 0.f, 0.f};
         if (!TRANS) {
-            const int r = r0 + (tid & 31) * 4, k = k0 + (tid >> 5) + q * 8;
+            const int r = r0 + (tid & (ROWS / 4 - 1)) * 4, k = k0 + tid / (ROWS / 4) + q * 8;
             if (k < kend) {
                 const float *p = src + (size_t)k * ld + r;
                 if (r + 3 < rmax) v = *reinterpret_cast<const float4 *>(p);
@@ -318,11 +319,11 @@ __device__ __forceinline__ void gemm_load(const float *__restrict__ src, int ld,
         reg[q] = v;
     }
 }
-template <bool TRANS> __device__ __forceinline__ void gemm_store(float *lds, int tid, const float4 (&reg)[2]) {
+template <bool TRANS, int ROWS> __device__ __forceinline__ void gemm_store(float *lds, int tid, const float4 (&reg)[2]) {
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < ROWS / 64; q++) {
         if (!TRANS) {
-            const int r = (tid & 31) * 4, k = (tid >> 5) + q * 8;
+            const int r = (tid & (ROWS / 4 - 1)) * 4, k = tid / (ROWS / 4) + q * 8;
             *reinterpret_cast<float4 *>(lds + k * GLD + r) = reg[q];
         } else {
             const int k = (tid & 3) * 4, r = (tid >> 2) + q * 64;
@@ -334,10 +335,11 @@ template <bool TRANS> __device__ __forceinline__ void gemm_store(float *lds, int
     }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int NI>
 __global__ __launch_bounds__(256) void k_gemm(int M, int Nn, int K, const float *__restrict__ A, int lda,
                                               const float *__restrict__ Bm, int ldb, float *__restrict__ C, int ldc,
                                               int kchunk, size_t slab_stride) {
+    constexpr int GBN = 64 * NI;
     __shared__ __attribute__((aligned(16))) float As[GBK * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[GBK * GLD];
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
@@ -347,39 +349,39 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int Nn, int K, const float 
     const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
     C += (size_t)blockIdx.z * slab_stride;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NI];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < NI; b++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
 
     float4 ra[2], rb[2];
     // op(A): TA=false -> A is M x K, m contiguous (direct); TA=true -> A stored K x M, k contiguous
     // op(B): TB=true  -> B stored Nn x K, n contiguous (direct); TB=false -> B is K x Nn, k contiguous
-    gemm_load<TA>(A, lda, m0, M, kbeg, kend, tid, ra);
-    gemm_load<!TB>(Bm, ldb, n0, Nn, kbeg, kend, tid, rb);
+    gemm_load<TA, GBM>(A, lda, m0, M, kbeg, kend, tid, ra);
+    gemm_load<!TB, GBN>(Bm, ldb, n0, Nn, kbeg, kend, tid, rb);
     for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-        gemm_store<TA>(As, tid, ra);
-        gemm_store<!TB>(Bs, tid, rb);
+        gemm_store<TA, GBM>(As, tid, ra);
+        gemm_store<!TB, GBN>(Bs, tid, rb);
         __syncthreads();
         if (k0 + GBK < kend) {
-            gemm_load<TA>(A, lda, m0, M, k0 + GBK, kend, tid, ra);
-            gemm_load<!TB>(Bm, ldb, n0, Nn, k0 + GBK, kend, tid, rb);
+            gemm_load<TA, GBM>(A, lda, m0, M, k0 + GBK, kend, tid, ra);
+            gemm_load<!TB, GBN>(Bm, ldb, n0, Nn, k0 + GBK, kend, tid, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 2) {
             const int k = kk + (l >> 5);
-            float af[2], bf[2];
+            float af[2], bf[NI];
             af[0] = As[k * GLD + wm * 64 + (l & 31)];
             af[1] = As[k * GLD + wm * 64 + 32 + (l & 31)];
-            bf[0] = Bs[k * GLD + wn * 64 + (l & 31)];
-            bf[1] = Bs[k * GLD + wn * 64 + 32 + (l & 31)];
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) bf[ni] = Bs[k * GLD + wn * 32 * NI + ni * 32 + (l & 31)];
 #pragma unroll
             for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                for (int ni = 0; ni < 2; ni++)
+                for (int ni = 0; ni < NI; ni++)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
         }
         __syncthreads();
@@ -388,11 +390,11 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int Nn, int K, const float 
 #pragma unroll
     for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++) {
+        for (int ni = 0; ni < NI; ni++) {
             const int m = m0 + wm * 64 + mi * 32 + (l & 31);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int n = n0 + wn * 64 + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                const int n = n0 + wn * 32 * NI + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
                 if (m < M && n < Nn) C[(size_t)n * ldc + m] = acc[mi][ni][r];
             }
         }
@@ -409,8 +411,16 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const float *__restrict__ s
     }
 }
 
+// tile width: 128 columns per workgroup unless that leaves most of the 256 CUs idle.  Long-K products
+// are split along K as well, so they tolerate fewer output tiles.
+static int gemm_pick_bn(int M, int Nn, int K) {
+    const int tiles128 = ((M + GBM - 1) / GBM) * ((Nn + 127) / 128);
+    if (K >= 2048) return tiles128 >= 32 ? 128 : 64;
+    return tiles128 >= 192 ? 128 : 64;
+}
 int gemm_pick_splits(int M, int Nn, int K) {
-    const int tiles = ((M + GBM - 1) / GBM) * ((Nn + GBN - 1) / GBN);
+    const int bn = gemm_pick_bn(M, Nn, K);
+    const int tiles = ((M + GBM - 1) / GBM) * ((Nn + bn - 1) / bn);
     int splits = 1;
     // aim for >= ~512 workgroups, keep >= 8 k-tiles per split
     while (tiles * splits < 512 && K / (splits * 2) >= 8 * GBK) splits *= 2;
@@ -423,16 +433,23 @@ void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const
     int kchunk = (K + splits - 1) / splits;
     kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
     splits = (K + kchunk - 1) / kchunk;
-    dim3 grid((M + GBM - 1) / GBM, (Nn + GBN - 1) / GBN, splits);
+    const int bn = gemm_pick_bn(M, Nn, K);
+    dim3 grid((M + GBM - 1) / GBM, (Nn + bn - 1) / bn, splits);
     float *out = splits > 1 ? slabs : C;
     const int ldo = splits > 1 ? M : ldc;
     const size_t stride = splits > 1 ? (size_t)M * Nn : 0;
-#define GEMM_LAUNCH(ta, tb) \
-    hipLaunchKernelGGL((k_gemm<ta, tb>), grid, dim3(256), 0, st, M, Nn, K, A, lda, B, ldb, out, ldo, kchunk, stride)
-    if (!TA && !TB) GEMM_LAUNCH(false, false);
-    else if (TA && !TB) GEMM_LAUNCH(true, false);
-    else if (!TA && TB) GEMM_LAUNCH(false, true);
-    else GEMM_LAUNCH(true, true);
+#define GEMM_LAUNCH(ta, tb, ni) \
+    hipLaunchKernelGGL((k_gemm<ta, tb, ni>), grid, dim3(256), 0, st, M, Nn, K, A, lda, B, ldb, out, ldo, kchunk, stride)
+#define GEMM_NI(ta, tb)              \
+    do {                             \
+        if (bn == 128) GEMM_LAUNCH(ta, tb, 2); \
+        else GEMM_LAUNCH(ta, tb, 1); \
+    } while (0)
+    if (!TA && !TB) GEMM_NI(false, false);
+    else if (TA && !TB) GEMM_NI(true, false);
+    else if (!TA && TB) GEMM_NI(false, true);
+    else GEMM_NI(true, true);
+#undef GEMM_NI
 #undef GEMM_LAUNCH
     if (splits > 1) {
         size_t total = (size_t)M * Nn;
@@ -504,8 +521,8 @@ void softmax_loss_dy(float *Y, float *P, const float *by, const int32_t *ti, flo
 
 // dby = rowsum(dY) (R/lstm.cc:227): fold the per-wave partials.  1024 threads = 64 float4 row groups
 // x 16 phases; phase q sums partials q, q+16, ... in order, then the 16 phase sums are added in order.
-__global__ __launch_bounds__(1024) void k_dby_finish(const float *__restrict__ part, int n_parts, float *__restrict__ dby) {
-    __shared__ float4 red[16][64];
+__device__ __forceinline__ void dby_finish_body(const float *__restrict__ part, int n_parts, float *__restrict__ dby,
+                                                float4 (*red)[64]) {
     const int m4 = threadIdx.x & 63, q = threadIdx.x >> 6;
     float4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
@@ -529,18 +546,23 @@ __global__ __launch_bounds__(1024) void k_dby_finish(const float *__restrict__ p
         reinterpret_cast<float4 *>(dby)[m4] = t;
     }
 }
-void dby_finish(const float *dby_part, int n_parts, float *dby, hipStream_t st) {
-    hipLaunchKernelGGL(k_dby_finish, dim3(1), dim3(1024), 0, st, dby_part, n_parts, dby);
-}
 
 // loss += surprisals.sum() / B per step (OV/lstm_eigen_opt/lstm.cc:249): float sum over the columns
 // of a step, divided by the (global) batch, accumulated over steps in double.
-__global__ __launch_bounds__(256) void k_loss_reduce(const float *__restrict__ colloss, int steps, int B, int Bg,
-                                                     double *__restrict__ out) {
-    __shared__ double part[256];
+// block 0: window loss; block 1 (when dby != null): dby = rowsum(dY) from the per-wave partials
+__global__ __launch_bounds__(1024) void k_loss_dby(const float *__restrict__ colloss, int steps, int B, int Bg,
+                                                   double *__restrict__ out, const float *__restrict__ dby_part,
+                                                   int n_parts, float *__restrict__ dby) {
+    __shared__ float4 red[16][64];
+    if (blockIdx.x == 1) {
+        dby_finish_body(dby_part, n_parts, dby, red);
+        return;
+    }
+    double *part = reinterpret_cast<double *>(&red[0][0]);
     double acc = 0.0;
-    for (int t = threadIdx.x; t < steps; t += 256) {
+    for (int t = threadIdx.x; t < steps; t += blockDim.x) {
         float s = 0.0f;
+#pragma unroll 8
         for (int b = 0; b < B; b++) s += colloss[(size_t)t * B + b];
         acc += (double)(s / (float)Bg);
     }
@@ -548,75 +570,269 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const float *__restrict__ c
     __syncthreads();
     if (threadIdx.x == 0) {
         double tot = 0.0;
-        for (int i = 0; i < 256; i++) tot += part[i];
+        for (int i = 0; i < (int)blockDim.x; i++) tot += part[i];
         out[0] = tot;
     }
 }
-void loss_reduce(const float *colloss, int steps, int B, int B_global, double *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, st, colloss, steps, B, B_global, out);
+void loss_reduce(const float *colloss, int steps, int B, int B_global, double *out, const float *dby_part, int n_parts,
+                 float *dby, hipStream_t st) {
+    hipLaunchKernelGGL(k_loss_dby, dim3(dby ? 2 : 1), dim3(1024), 0, st, colloss, steps, B, B_global, out, dby_part,
+                       n_parts, dby);
 }
 
 // ------------------------------------------------------------------------------------------------
-// dW_db: dW += dg * x^T with one-hot x (R/lstm.cc:251) = per-input-byte sums of DG columns;
-// db += dg (R/lstm.cc:252) = sum over all buckets.  128 threads = 16 rows x 8 column phases.
-// LDS table acc[257][128]: word (v, tid) is only ever touched by thread tid -> deterministic.
+// dW, db: dW += dg * x^T with one-hot x (R/lstm.cc:251) = per-input-byte sums of DG columns;
+// db += dg (R/lstm.cc:252) = sum over all buckets.  Three deterministic passes:
+//   k_bucket_columns : stable counting sort of the T column ids by input byte (bucket 256 = empty
+//                      column), cut into chunks of <= DW_CHUNK columns                 (one workgroup)
+//   k_dW_segsum      : one workgroup per chunk sums its columns in order; each column is a contiguous
+//                      4N-float run, read with float4 loads                           (HBM/L2 bound)
+//   k_dW_finish      : per (bucket, 1024 rows) adds the bucket's chunk partials in order -> dW;
+//                      k_db_finish adds the 257 bucket totals per row -> db
 // ------------------------------------------------------------------------------------------------
-constexpr int DW_ROWS = 16, DW_COPIES = 8, DW_THREADS = DW_ROWS * DW_COPIES;
-__global__ __launch_bounds__(DW_THREADS) void k_dW_db(const float *__restrict__ DG, const int32_t *__restrict__ xi, int T,
-                                                      int G4, float *__restrict__ dW, float *__restrict__ db) {
-    extern __shared__ __attribute__((aligned(16))) float acc[]; // 257 * 128 floats
-    const int tid = threadIdx.x, r = tid & (DW_ROWS - 1), q = tid / DW_ROWS;
-    const int r0 = blockIdx.x * DW_ROWS;
-    for (int i = tid; i < 257 * DW_THREADS; i += DW_THREADS) acc[i] = 0.0f;
+constexpr int SORT_NCH = 64; // column ranges processed sequentially by one thread each
+__global__ __launch_bounds__(1024) void k_bucket_columns(const int32_t *__restrict__ xi, int T,
+                                                         int32_t *__restrict__ perm, int32_t *__restrict__ chunk_start,
+                                                         int32_t *__restrict__ bucket_chunk, int32_t *__restrict__ n_chunks) {
+    __shared__ int hist[SORT_NCH][257];
+    __shared__ int bstart[258];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SORT_NCH * 257; i += blockDim.x) (&hist[0][0])[i] = 0;
     __syncthreads();
-    const float *src = DG + r0 + r;
-    constexpr int UN = 8; // columns in flight per thread
-    int col = q;
-    for (; col + (UN - 1) * DW_COPIES < T; col += UN * DW_COPIES) {
-        int v[UN];
-        float val[UN];
-#pragma unroll
-        for (int i = 0; i < UN; i++) {
-            v[i] = xi[col + i * DW_COPIES];
-            val[i] = src[(size_t)(col + i * DW_COPIES) * G4];
+    const int per = (T + SORT_NCH - 1) / SORT_NCH;
+    const int c0 = tid * per, c1 = (c0 + per < T) ? c0 + per : T;
+    if (tid < SORT_NCH)
+        for (int c = c0; c < c1; c++) {
+            int v = xi[c];
+            v = v < 0 ? 256 : v;
+            hist[tid][v]++;
         }
+    __syncthreads();
+    if (tid < 257) { // exclusive scan over the ranges, per bucket
+        int run = 0;
+        for (int ch = 0; ch < SORT_NCH; ch++) {
+            const int n = hist[ch][tid];
+            hist[ch][tid] = run;
+            run += n;
+        }
+        bstart[tid + 1] = run; // bucket size for now
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0, chunks = 0;
+        bstart[0] = 0;
+        for (int v = 0; v < 257; v++) {
+            const int n = bstart[v + 1];
+            bucket_chunk[v] = chunks;
+            for (int o = 0; o < n; o += DW_CHUNK) chunk_start[chunks++] = run + o;
+            run += n;
+            bstart[v + 1] = run;
+        }
+        bucket_chunk[257] = chunks;
+        chunk_start[chunks] = T;
+        n_chunks[0] = chunks;
+    }
+    __syncthreads();
+    if (tid < SORT_NCH)
+        for (int c = c0; c < c1; c++) {
+            int v = xi[c];
+            v = v < 0 ? 256 : v;
+            perm[bstart[v] + hist[tid][v]++] = c;
+        }
+}
+
+// Fast path for T <= 16384: rank-based stable counting sort in one workgroup.  Columns are taken in
+// chunks of 64 (one wave); inside a chunk a lane's rank among equal bytes comes from a 64-step
+// readlane sweep, per-chunk counts go to an LDS table, one thread per byte turns them into chunk
+// offsets, and every column then knows its slot: bucket start + chunk offset + rank.  Order inside a
+// bucket is ascending column, so every float sum downstream has a fixed order.
+constexpr int RANK_SLOTS = 16; // chunks per wave: 16 waves x 16 slots x 64 columns = 16384 columns
+__global__ __launch_bounds__(1024) void k_bucket_columns_rank(const int32_t *__restrict__ xi, int T,
+                                                              int32_t *__restrict__ perm,
+                                                              int32_t *__restrict__ chunk_start,
+                                                              int32_t *__restrict__ bucket_chunk,
+                                                              int32_t *__restrict__ n_chunks) {
+    extern __shared__ unsigned short hist[]; // [nch][257]
+    __shared__ int bstart[258];
+    __shared__ int bchunk[258];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nch = (T + 63) / 64;
+    for (int i = tid; i < nch * 257; i += 1024) hist[i] = 0;
+    __syncthreads();
+    int keys[RANK_SLOTS], ranks[RANK_SLOTS];
 #pragma unroll
-        for (int i = 0; i < UN; i++) {
-            const int vv = v[i] < 0 ? 256 : v[i];
-            atomicAdd(&acc[vv * DW_THREADS + tid], val[i]); // ds_add_f32 on a word private to this thread
+    for (int s = 0; s < RANK_SLOTS; s++) {
+        const int c = w + 16 * s;
+        keys[s] = 257;
+        ranks[s] = 0;
+        if (c < nch) { // wave-uniform
+            const int col = c * 64 + lane;
+            int key = 257;
+            if (col < T) {
+                key = xi[col];
+                key = key < 0 ? 256 : key;
+            }
+            int rank = 0, later = 0;
+            for (int k = 0; k < 64; k++) {
+                const int ok = __shfl(key, k, 64);
+                const int same = ok == key;
+                rank += same & (k < lane);
+                later |= same & (k > lane);
+            }
+            keys[s] = key;
+            ranks[s] = rank;
+            if (key < 257 && !later) hist[c * 257 + key] = (unsigned short)(rank + 1);
         }
     }
-    for (; col < T; col += DW_COPIES) {
-        int v = xi[col];
-        v = v < 0 ? 256 : v;
-        atomicAdd(&acc[v * DW_THREADS + tid], src[(size_t)col * G4]);
+    __syncthreads();
+    if (tid < 257) { // chunk counts -> chunk offsets inside the bucket; bucket size
+        int run = 0;
+        for (int c = 0; c < nch; c++) {
+            const int n = hist[c * 257 + tid];
+            hist[c * 257 + tid] = (unsigned short)run;
+            run += n;
+        }
+        bstart[tid + 1] = run;
     }
     __syncthreads();
-    // fold the 8 phases in fixed order; keep bucket totals in slot 0 for the db pass
-    for (int i = tid; i < 257 * DW_ROWS; i += DW_THREADS) {
-        const int v = i / DW_ROWS, rr = i % DW_ROWS;
-        float s = acc[v * DW_THREADS + rr];
+    if (tid == 0) {
+        int run = 0, chunks = 0;
+        bstart[0] = 0;
+        for (int v = 0; v < 257; v++) {
+            const int n = bstart[v + 1];
+            bchunk[v] = chunks;
+            chunks += (n + DW_CHUNK - 1) / DW_CHUNK;
+            run += n;
+            bstart[v + 1] = run;
+        }
+        bchunk[257] = chunks;
+        chunk_start[chunks] = T;
+        n_chunks[0] = chunks;
+    }
+    __syncthreads();
+    if (tid < 258) bucket_chunk[tid] = bchunk[tid];
+    if (tid < 257) {
+        int q = bchunk[tid];
+        for (int o = bstart[tid]; o < bstart[tid + 1]; o += DW_CHUNK) chunk_start[q++] = o;
+    }
 #pragma unroll
-        for (int c = 1; c < DW_COPIES; c++) s += acc[v * DW_THREADS + c * DW_ROWS + rr];
-        if (v < 256) dW[(size_t)v * G4 + r0 + rr] = s;
-        acc[v * DW_THREADS + rr] = s;
-    }
-    __syncthreads();
-    if (tid < DW_ROWS) {
-        float s = 0.0f;
-        for (int v = 0; v < 257; v++) s += acc[v * DW_THREADS + tid];
-        db[r0 + tid] = s;
+    for (int s = 0; s < RANK_SLOTS; s++) {
+        const int c = w + 16 * s;
+        if (c < nch && keys[s] < 257) perm[bstart[keys[s]] + hist[c * 257 + keys[s]] + ranks[s]] = c * 64 + lane;
     }
 }
-void dW_db(const float *DG, const int32_t *xi, int T, int G4, float *dW, float *db, hipStream_t st) {
-    static bool attr_set = false;
-    const size_t lds = 257 * DW_THREADS * sizeof(float);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dW_db), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_set = true;
+
+__global__ __launch_bounds__(256) void k_dW_segsum(const float *__restrict__ DG, int G4, const int32_t *__restrict__ perm,
+                                                   const int32_t *__restrict__ chunk_start,
+                                                   const int32_t *__restrict__ bucket_chunk,
+                                                   const int32_t *__restrict__ n_chunks, float *__restrict__ part) {
+    const int chunk = blockIdx.x;
+    if (chunk >= n_chunks[0]) return;
+    int c0 = chunk_start[chunk], c1 = chunk_start[chunk + 1];
+    // a chunk never crosses a bucket: the next bucket's first chunk starts exactly at this bucket's end
+    if (c1 - c0 > DW_CHUNK) c1 = c0 + DW_CHUNK;
+    (void)bucket_chunk;
+    for (int r4 = threadIdx.x; r4 < G4 / 4; r4 += blockDim.x) {
+        float4 s = {0.f, 0.f, 0.f, 0.f};
+        int i = c0;
+        for (; i + 4 <= c1; i += 4) {
+            const float4 v0 = reinterpret_cast<const float4 *>(DG + (size_t)perm[i] * G4)[r4];
+            const float4 v1 = reinterpret_cast<const float4 *>(DG + (size_t)perm[i + 1] * G4)[r4];
+            const float4 v2 = reinterpret_cast<const float4 *>(DG + (size_t)perm[i + 2] * G4)[r4];
+            const float4 v3 = reinterpret_cast<const float4 *>(DG + (size_t)perm[i + 3] * G4)[r4];
+            s.x = (((s.x + v0.x) + v1.x) + v2.x) + v3.x;
+            s.y = (((s.y + v0.y) + v1.y) + v2.y) + v3.y;
+            s.z = (((s.z + v0.z) + v1.z) + v2.z) + v3.z;
+            s.w = (((s.w + v0.w) + v1.w) + v2.w) + v3.w;
+        }
+        for (; i < c1; i++) {
+            const float4 v = reinterpret_cast<const float4 *>(DG + (size_t)perm[i] * G4)[r4];
+            s.x += v.x;
+            s.y += v.y;
+            s.z += v.z;
+            s.w += v.w;
+        }
+        reinterpret_cast<float4 *>(part + (size_t)chunk * G4)[r4] = s;
     }
-    hipLaunchKernelGGL(k_dW_db, dim3(G4 / DW_ROWS), dim3(DW_THREADS), lds, st, DG, xi, T, G4, dW, db);
+}
+
+// grid (257, G4/1024): bucket v, rows [1024*by, +1024); bucket 256 (empty columns) only feeds db
+__global__ __launch_bounds__(256) void k_dW_finish(const float *__restrict__ part, const int32_t *__restrict__ bucket_chunk,
+                                                   int G4, float *__restrict__ dW, float *__restrict__ dWnull) {
+    const int v = blockIdx.x;
+    const int r4 = blockIdx.y * 256 + threadIdx.x;
+    if (r4 >= G4 / 4) return;
+    const int q0 = bucket_chunk[v], q1 = bucket_chunk[v + 1];
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    int q = q0;
+    for (; q + 4 <= q1; q += 4) { // four partial rows in flight, added in order
+        const float4 p0 = reinterpret_cast<const float4 *>(part + (size_t)q * G4)[r4];
+        const float4 p1 = reinterpret_cast<const float4 *>(part + (size_t)(q + 1) * G4)[r4];
+        const float4 p2 = reinterpret_cast<const float4 *>(part + (size_t)(q + 2) * G4)[r4];
+        const float4 p3 = reinterpret_cast<const float4 *>(part + (size_t)(q + 3) * G4)[r4];
+        s.x = (((s.x + p0.x) + p1.x) + p2.x) + p3.x;
+        s.y = (((s.y + p0.y) + p1.y) + p2.y) + p3.y;
+        s.z = (((s.z + p0.z) + p1.z) + p2.z) + p3.z;
+        s.w = (((s.w + p0.w) + p1.w) + p2.w) + p3.w;
+    }
+    for (; q < q1; q++) {
+        const float4 p = reinterpret_cast<const float4 *>(part + (size_t)q * G4)[r4];
+        s.x += p.x;
+        s.y += p.y;
+        s.z += p.z;
+        s.w += p.w;
+    }
+    float *dst = v < 256 ? dW + (size_t)v * G4 : dWnull;
+    reinterpret_cast<float4 *>(dst)[r4] = s;
+}
+// db[r] = sum over the 257 buckets: 64 rows x 4 bucket phases per workgroup, phases folded in order
+__global__ __launch_bounds__(256) void k_db_finish(const float *__restrict__ dW, const float *__restrict__ dWnull, int G4,
+                                                   float *__restrict__ db) {
+    __shared__ float red[4][64];
+    const int rr = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int r = blockIdx.x * 64 + rr;
+    float s = 0.0f;
+    if (r < G4) {
+#pragma unroll 8
+        for (int v = ph * 64; v < ph * 64 + 64; v++) s += dW[(size_t)v * G4 + r];
+    }
+    red[ph][rr] = s;
+    __syncthreads();
+    if (ph == 0 && r < G4) db[r] = (((red[0][rr] + red[1][rr]) + red[2][rr]) + red[3][rr]) + dWnull[r];
+}
+
+size_t dW_scratch_bytes(int T, int G4) {
+    const size_t max_chunks = (size_t)T / DW_CHUNK + 258;
+    // perm[T] | chunk_start[max_chunks+1] | bucket_chunk[258] | n_chunks[1] | part[max_chunks][G4] | dWnull[G4]
+    return sizeof(int32_t) * ((size_t)T + max_chunks + 1 + 258 + 4) + sizeof(float) * (max_chunks * G4 + G4) + 64;
+}
+void dW_db(const float *DG, const int32_t *xi, int T, int G4, float *dW, float *db, void *scratch, hipStream_t st) {
+    const int max_chunks = T / DW_CHUNK + 258;
+    int32_t *perm = reinterpret_cast<int32_t *>(scratch);
+    int32_t *chunk_start = perm + T;
+    int32_t *bucket_chunk = chunk_start + max_chunks + 1;
+    int32_t *n_chunks = bucket_chunk + 258;
+    size_t off = sizeof(int32_t) * ((size_t)T + max_chunks + 1 + 258 + 4);
+    off = (off + 63) & ~(size_t)63;
+    float *part = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + off);
+    float *dWnull = part + (size_t)max_chunks * G4;
+    if (T <= 64 * 16 * RANK_SLOTS) {
+        const size_t lds = (size_t)((T + 63) / 64) * 257 * sizeof(unsigned short);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_columns_rank),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_bucket_columns_rank, dim3(1), dim3(1024), lds, st, xi, T, perm, chunk_start, bucket_chunk,
+                           n_chunks);
+    } else {
+        hipLaunchKernelGGL(k_bucket_columns, dim3(1), dim3(1024), 0, st, xi, T, perm, chunk_start, bucket_chunk, n_chunks);
+    }
+    hipLaunchKernelGGL(k_dW_segsum, dim3(max_chunks), dim3(256), 0, st, DG, G4, perm, chunk_start, bucket_chunk, n_chunks,
+                       part);
+    hipLaunchKernelGGL(k_dW_finish, dim3(257, (G4 / 4 + 255) / 256), dim3(256), 0, st, part, bucket_chunk, G4, dW, dWnull);
+    hipLaunchKernelGGL(k_db_finish, dim3((G4 + 63) / 64), dim3(256), 0, st, dW, dWnull, G4, db);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -628,8 +844,13 @@ __device__ __forceinline__ float adagrad1(float p, float d, float &m, float lr) 
     const float den = sqrtf((float)((double)m + 1e-10));
     return p - lr * (d / den);
 }
+// The U block additionally refreshes the two MFMA fragment images (what k_pack_U builds), so the
+// forward of the next window needs no separate repack launch.  A float4 here is 4 consecutive gate
+// rows of one column k of U: one float4 of Ubwd, four scalars of Ufwd.
 __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const float *__restrict__ dP,
-                                                 float *__restrict__ mem, size_t n4, float lr) {
+                                                 float *__restrict__ mem, size_t n4, float lr, size_t u_off4, int N,
+                                                 float4 *__restrict__ Ufwd, float4 *__restrict__ Ubwd) {
+    const size_t u_n4 = (size_t)N * N; // float4 count of U
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 p = reinterpret_cast<float4 *>(P)[i];
         const float4 d = reinterpret_cast<const float4 *>(dP)[i];
@@ -640,13 +861,31 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const fl
         p.w = adagrad1(p.w, d.w, m.w, lr);
         reinterpret_cast<float4 *>(P)[i] = p;
         reinterpret_cast<float4 *>(mem)[i] = m;
+        if (Ufwd != nullptr && i >= u_off4 && i < u_off4 + u_n4) {
+            const size_t e = i - u_off4;        // float4 index inside U: rows 4*(e % N) .. +3 of column e / N
+            const int r = 4 * (int)(e % N), k = (int)(e / N);
+            // Ubwd[kb][r4][l] = U[16*r4 + 4*(l>>4) + 0..3][16*kb + (l&15)]
+            Ubwd[((size_t)(k >> 4) * (N / 4) + (r >> 4)) * 64 + (((r & 15) >> 2) << 4) + (k & 15)] = p;
+            // Ufwd[jb][k4][l].i = U[(l&3)*N + 4*jb + ((l&15)>>2)][16*k4 + 4*(l>>4) + i]
+            const int gate = r / N, hid = r % N; // 4 rows share the gate (N % 4 == 0)
+            const int k4 = k >> 4, kq = (k & 15) >> 2, ki = k & 3;
+            float *uf = reinterpret_cast<float *>(Ufwd);
+            const float pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+            for (int dlt = 0; dlt < 4; dlt++) {
+                const int h = hid + dlt, jb = h >> 2, jj = h & 3;
+                const int l = (kq << 4) | (jj << 2) | gate;
+                uf[(((size_t)jb * (N / 16) + k4) * 64 + l) * 4 + ki] = pv[dlt];
+            }
+        }
     }
 }
-void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, hipStream_t st) {
+void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
+             hipStream_t st) {
     const size_t n4 = n / 4; // the flat block is a multiple of 4 floats (M = 256, N % 16 == 0)
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adagrad, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr);
+    hipLaunchKernelGGL(k_adagrad, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -665,6 +904,13 @@ __global__ __launch_bounds__(1024) void k_slide_window(const uint8_t *__restrict
                                                        int32_t *__restrict__ xi, int32_t *__restrict__ ti,
                                                        float *__restrict__ H, float *__restrict__ C, int S, int B,
                                                        int NB4) {
+    if (blockIdx.x > 0) { // carry: column 0 of the next window is column 1 of this one (opt:205-206)
+        for (int i = (blockIdx.x - 1) * blockDim.x + threadIdx.x; i < NB4; i += (gridDim.x - 1) * blockDim.x) {
+            reinterpret_cast<float4 *>(H)[i] = reinterpret_cast<const float4 *>(H)[NB4 + i];
+            reinterpret_cast<float4 *>(C)[i] = reinterpret_cast<const float4 *>(C)[NB4 + i];
+        }
+        return;
+    }
     const int head = (*headp + 1) % S;
     const int last = (head + S - 1) % S, prev = (head + S - 2) % S;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
@@ -676,11 +922,6 @@ __global__ __launch_bounds__(1024) void k_slide_window(const uint8_t *__restrict
         Tr[last * B + b] = event;
         Xr[last * B + b] = Tr[prev * B + b];
     }
-    // carry: column 0 of the next window is column 1 of this one
-    for (int i = threadIdx.x; i < NB4; i += blockDim.x) {
-        reinterpret_cast<float4 *>(H)[i] = reinterpret_cast<const float4 *>(H)[NB4 + i];
-        reinterpret_cast<float4 *>(C)[i] = reinterpret_cast<const float4 *>(C)[NB4 + i];
-    }
     __syncthreads();
     for (int i = threadIdx.x; i < S * B; i += blockDim.x) {
         const int t = i / B, b = i - t * B;
@@ -688,12 +929,16 @@ __global__ __launch_bounds__(1024) void k_slide_window(const uint8_t *__restrict
         xi[i] = Xr[row * B + b];
         ti[i] = Tr[row * B + b];
     }
+    __syncthreads();
     if (threadIdx.x == 0) *headp = head;
 }
 void slide_window(const uint8_t *text, uint64_t len, uint64_t *pos, int32_t *Xr, int32_t *Tr, int32_t *headp,
                   int32_t *xi, int32_t *ti, float *H, float *C, int S, int B, int N, hipStream_t st) {
-    hipLaunchKernelGGL(k_slide_window, dim3(1), dim3(1024), 0, st, text, len, pos, Xr, Tr, headp, xi, ti, H, C, S, B,
-                       N * B / 4);
+    const int nb4 = N * B / 4;
+    int copy_blocks = (nb4 + 1023) / 1024;
+    if (copy_blocks > 32) copy_blocks = 32;
+    hipLaunchKernelGGL(k_slide_window, dim3(1 + copy_blocks), dim3(1024), 0, st, text, len, pos, Xr, Tr, headp, xi, ti, H,
+                       C, S, B, nb4);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -90,6 +90,7 @@ struct lstm_hip_ctx {
     bool packed = false;
     float *H = nullptr, *C = nullptr, *G = nullptr, *DG = nullptr, *Y = nullptr, *Pr = nullptr, *DHy = nullptr;
     float *dcnext = nullptr, *colloss = nullptr, *dby_part = nullptr, *slabs = nullptr;
+    char *dw_scratch = nullptr;
     int n_dby_parts = 0;
     int splits_dWhy = 1, splits_dU = 1;
     int32_t *xi = nullptr, *ti = nullptr;            // flat [S][B] indices the kernels read
@@ -102,10 +103,15 @@ struct lstm_hip_ctx {
     uint64_t *pos = nullptr;
     int32_t global_B = 0;
     bool fwd_done = false;
+    bool dby_done = false;       // dby already produced by the loss launch of this window
     bool persistent = false;     // default engine; false = one launch per timestep
     unsigned *cnt = nullptr;     // [2][persistent_counter_bytes]: fwd region, bwd region
     unsigned *abortp = nullptr;  // set by a timed-out spin inside a persistent kernel
     size_t cnt_bytes = 0;
+    unsigned long long *stamps = nullptr; // LSTM_HIP_DEBUG_STAMPS: [2][S][8] s_memtime values of the last forward
+    unsigned long long *Hg = nullptr; // h_t as {value, tag} granules for the forward hand-off
+    unsigned window_serial = 0;
+    unsigned fwd_epoch = 0, bwd_epoch = 0; // launches so far on the cumulative hand-off counters       // epoch_base = S * serial; tags of earlier windows never match
 
     void *comm = nullptr;
     int nranks = 1, rank = 0;
@@ -168,6 +174,8 @@ int check_abort(lstm_hip_ctx *h) {
     HIP_TRY(hipStreamSynchronize(h->st));
     if (flag != 0) {
         HIP_TRY(hipMemsetAsync(h->abortp, 0, sizeof(unsigned), h->st));
+        HIP_TRY(hipMemsetAsync(h->cnt, 0, 2 * h->cnt_bytes, h->st)); // counters are inconsistent after an abort
+        h->fwd_epoch = h->bwd_epoch = 0;
         return fail(LSTM_HIP_ESTATE, "a persistent recurrence kernel timed out waiting for a hand-off (results invalid)");
     }
     return 0;
@@ -181,9 +189,24 @@ int do_forward(lstm_hip_ctx *h) {
         h->packed = true;
     }
     if (h->persistent) {
-        HIP_TRY(hipMemsetAsync(h->cnt, 0, h->cnt_bytes, h->st));
-        RUN(K_FWD_PERSIST, fwd_persistent(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->cnt,
-                                          h->abortp, N, S, B, fast, h->st));
+        if (!(h->cfg.flags & LSTM_HIP_GRANULE_HANDOFF)) {
+            if (h->fwd_epoch >= (1u << 26)) { // keep epoch * arrivals inside 32 bits
+                HIP_TRY(hipMemsetAsync(h->cnt, 0, h->cnt_bytes, h->st));
+                h->fwd_epoch = 0;
+            }
+            h->fwd_epoch++;
+            RUN(K_FWD_PERSIST, fwd_persistent(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->cnt,
+                                              h->abortp, h->fwd_epoch, N, S, B, fast, h->st, h->stamps));
+        } else {
+            h->window_serial++;
+            if ((unsigned long long)(h->window_serial + 1) * (unsigned)S >= 0xffffffffull) { // tag space exhausted: start over
+                HIP_TRY(hipMemsetAsync(h->Hg, 0, sizeof(unsigned long long) * (size_t)S * B * N, h->st));
+                h->window_serial = 1;
+            }
+            RUN(K_FWD_PERSIST, fwd_persistent_granules(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->Hg,
+                                                       h->xi, h->abortp, h->window_serial * (unsigned)S, N, S, B, fast,
+                                                       h->st));
+        }
     } else
     for (int t = 1; t < S; t++) {
         RUN(K_FWD_STEP, fwd_step(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H + (size_t)(t - 1) * N * B,
@@ -203,15 +226,22 @@ int do_backward(lstm_hip_ctx *h) {
     const int N = h->cfg.N, B = h->cfg.B, S = h->cfg.S, G4 = 4 * N, T = h->T;
     if (!h->fwd_done) return fail(LSTM_HIP_ESTATE, "backward called before forward");
     float *dY = h->Y + (size_t)256 * B;
-    // dby = rowsum(dY)                 R/lstm.cc:227
-    RUN(K_DBY, dby_finish(h->dby_part, h->n_dby_parts, h->dP + h->pl.by, h->st));
+    // dby = rowsum(dY) (R/lstm.cc:227): folded with the loss when the loop runs on the device
+    if (!h->dby_done)
+        RUN(K_DBY, loss_reduce(h->colloss, S - 1, B, h->global_B, h->d_loss, h->dby_part, h->n_dby_parts,
+                               h->dP + h->pl.by, h->st));
+    h->dby_done = false;
     // DHy = Why^T * dY                 R/lstm.cc:228, all steps
     RUN(K_GEMM_DHY, gemm(true, false, N, T, 256, h->P + h->pl.Why, 256, dY, 256, h->DHy + (size_t)N * B, N, 1, nullptr,
                          h->st));
     if (h->persistent) {
         unsigned *cb = h->cnt + h->cnt_bytes / sizeof(unsigned);
-        HIP_TRY(hipMemsetAsync(cb, 0, h->cnt_bytes, h->st));
-        RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, cb, h->abortp, N, S, B, h->st));
+        if (h->bwd_epoch >= (1u << 26)) {
+            HIP_TRY(hipMemsetAsync(cb, 0, h->cnt_bytes, h->st));
+            h->bwd_epoch = 0;
+        }
+        h->bwd_epoch++;
+        RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, cb, h->abortp, h->bwd_epoch, N, S, B, h->st));
     } else {
     HIP_TRY(hipMemsetAsync(h->dcnext, 0, sizeof(float) * N * B, h->st)); // R/lstm.cc:216-217
     for (int t = S - 1; t >= 1; t--) {
@@ -227,7 +257,7 @@ int do_backward(lstm_hip_ctx *h) {
     RUN(K_GEMM_DU, gemm(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->dP + h->pl.U, G4, h->splits_dU,
                         h->slabs, h->st));
     // dW, db                           R/lstm.cc:251-252
-    RUN(K_DW_DB, dW_db(h->DG + (size_t)G4 * B, h->xi + B, T, G4, h->dP + h->pl.W, h->dP + h->pl.b, h->st));
+    RUN(K_DW_DB, dW_db(h->DG + (size_t)G4 * B, h->xi + B, T, G4, h->dP + h->pl.W, h->dP + h->pl.b, h->dw_scratch, h->st));
     return 0;
 }
 
@@ -241,8 +271,8 @@ int do_allreduce(lstm_hip_ctx *h) {
 }
 
 int do_adagrad(lstm_hip_ctx *h, double lr) {
-    RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->st));
-    h->packed = false;
+    RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd, h->Ubwd, h->st));
+    h->packed = true; // the U images were refreshed by the same launch
     return 0;
 }
 
@@ -309,6 +339,7 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
         size_t a = (size_t)h->splits_dWhy * 256 * N, b = (size_t)h->splits_dU * G4 * N;
         ALLOC(h->slabs, a > b ? a : b);
     }
+    ALLOC(h->dw_scratch, dW_scratch_bytes(h->T, (int)G4));
     ALLOC(h->xi, S * B);
     ALLOC(h->ti, S * B);
     ALLOC(h->Xr, S * B);
@@ -324,6 +355,8 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
     ALLOC(h->cnt, 2 * h->cnt_bytes / sizeof(unsigned));
     ALLOC(h->abortp, 4);
     h->persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) && persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount);
+    if (h->persistent && (cfg->flags & LSTM_HIP_GRANULE_HANDOFF)) ALLOC(h->Hg, S * B * N);
+    if (h->persistent && (cfg->flags & LSTM_HIP_DEBUG_STAMPS)) ALLOC(h->stamps, 2 * S * 8);
     HIP_TRY(hipDeviceSynchronize());
     *out = h;
     return 0;
@@ -335,7 +368,7 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     (void)hipStreamSynchronize(h->st);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
-                    h->colloss, h->dby_part, h->slabs, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->d_loss, h->d_losses, h->text, h->pos};
+                    h->colloss, h->dby_part, h->slabs, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->Hg, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -447,7 +480,7 @@ int lstm_hip_loss(lstm_hip_t *h, double *loss_bits) {
     CHECK(h);
     if (!loss_bits) return fail(LSTM_HIP_EINVAL, "loss: null pointer");
     if (!h->fwd_done) return fail(LSTM_HIP_ESTATE, "loss called before forward");
-    RUN(K_LOSS, loss_reduce(h->colloss, h->cfg.S - 1, h->cfg.B, h->global_B, h->d_loss, h->st));
+    RUN(K_LOSS, loss_reduce(h->colloss, h->cfg.S - 1, h->cfg.B, h->global_B, h->d_loss, nullptr, 0, nullptr, h->st));
     HIP_TRY(hipMemcpyAsync(loss_bits, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
     return check_abort(h);
@@ -547,7 +580,9 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
                                   h->cfg.S, h->cfg.B, h->cfg.N, h->st));
         int rc = 0;
         if ((rc = do_forward(h))) return rc;
-        RUN(K_LOSS, loss_reduce(h->colloss, h->cfg.S - 1, h->cfg.B, h->global_B, h->d_losses + i, h->st));
+        RUN(K_LOSS, loss_reduce(h->colloss, h->cfg.S - 1, h->cfg.B, h->global_B, h->d_losses + i, h->dby_part,
+                                h->n_dby_parts, h->dP + h->pl.by, h->st));
+        h->dby_done = true;
         if ((rc = do_backward(h))) return rc;
         if ((rc = do_allreduce(h))) return rc;
         if ((rc = do_adagrad(h, learning_rate))) return rc;
@@ -601,6 +636,15 @@ int lstm_hip_sample(lstm_hip_t *h, float *h0, float *c0, const double *u, int32_
     (void)hipFree(d_hc);
     (void)hipFree(d_u);
     (void)hipFree(d_out);
+    return 0;
+}
+
+int lstm_hip_debug_stamps(lstm_hip_t *h, uint64_t *out, size_t count) {
+    CHECK(h);
+    if (!h->stamps) return fail(LSTM_HIP_ESTATE, "handle was not created with LSTM_HIP_DEBUG_STAMPS on a supported shape");
+    const size_t have = (size_t)2 * h->cfg.S * 8;
+    HIP_TRY(hipMemcpyAsync(out, h->stamps, sizeof(uint64_t) * (count < have ? count : have), hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipStreamSynchronize(h->st));
     return 0;
 }
 

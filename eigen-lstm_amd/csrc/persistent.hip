@@ -19,12 +19,14 @@
 // does a relaxed agent-scope atomic add on a counter sharded 8 ways (cnt[t][g][p&7]) so arrivals do
 // not serialise on one address.  A consumer's wave 0 polls the 8 shards with sc1 loads until every
 // shard has all its arrivals, a workgroup barrier follows, and only then does any wave read h_t, with
-// sc1 loads (never through L1).  Counters are zeroed by a memset node before every launch.  Every
+// sc1 loads (never through L1).  Counters are never reset: launch number e waits for e x arrivals.  Every
 // spin is bounded; on time-out a global abort word makes every workgroup leave, and the host reports it.
 //
 // Residency: all workgroups must be co-resident (they wait on each other); the host checks the grid
 // against the occupancy of the device and falls back to the per-step engine otherwise.
 #include "kernels.h"
+
+#include <cstdlib>
 
 namespace lstmk {
 
@@ -68,8 +70,9 @@ __device__ __forceinline__ void st_sc1(float4 f, __amdgpu_buffer_rsrc_t r, int b
 
 // wave-level wait until all `n_prod` producers (sharded by id & 7) have arrived at `cp`.
 // Returns false on time-out / abort.  Called by one whole wave.
-__device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, unsigned *abortp, int lane) {
-    const unsigned expect = lane < 8 ? (unsigned)((n_prod - lane + 7) / 8) : 0u;
+// Counters are never reset: launch number `epoch` (1, 2, ...) waits for epoch * (arrivals per launch).
+__device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, unsigned epoch, unsigned *abortp, int lane) {
+    const unsigned expect = lane < 8 ? epoch * (unsigned)((n_prod - lane + 7) / 8) : 0u;
     for (int spins = 0;; spins++) {
         unsigned v = 0;
         if (lane < 8) v = __hip_atomic_load(cp + lane * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -85,11 +88,17 @@ __device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, un
 // ------------------------------------------------------------------------------------------------
 // forward recurrence, t = 1..S-1, N = 64*NK4W.  grid (N/4, ceil(B/16)), 256 threads.
 // ------------------------------------------------------------------------------------------------
-template <int NK4W, bool FAST>
+// STAMP builds record s_memtime at five points of every step for two workgroups (diagnostics only:
+// the stamps go to a buffer nothing else reads; the shipped path is the STAMP=false instantiation).
+#define STAMP_AT(k)                                                                      \
+    if (STAMP && l == 0 && w == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
+        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+template <int NK4W, bool FAST, bool STAMP = false>
 __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict__ Ufwd, const float *__restrict__ W,
                                                         const float *__restrict__ bias, float *H, float *__restrict__ C,
                                                         float *__restrict__ G, const int32_t *__restrict__ xi,
-                                                        unsigned *cnt, unsigned *abortp, int S, int B) {
+                                                        unsigned *cnt, unsigned *abortp, unsigned epoch, int S, int B,
+                                                        int stagger, unsigned long long *stamps = nullptr) {
     constexpr int N = 64 * NK4W, G4 = 4 * N, nk4 = N / 16;
     __shared__ float red[4 * 4 * 64];
     __shared__ int s_abort;
@@ -111,9 +120,14 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
     const __amdgpu_buffer_rsrc_t rH = make_rsrc(H, (size_t)S * N * B * sizeof(float));
     if (threadIdx.x == 0) s_abort = 0;
     __syncthreads();
+    // Stagger the column groups in time: their recurrences are independent, and every step of a
+    // group is a burst of device-scope loads (all its workgroups pull the same h_{t-1}); offsetting
+    // group g by g/NG of a step keeps the groups out of each other's burst.
+    for (int i = 0; i < g * stagger; i++) __builtin_amdgcn_s_sleep(32);
 
     for (int t = 1; t < S; t++) {
         float wx[4] = {0.f, 0.f, 0.f, 0.f};
+        STAMP_AT(0)
         if (w == 0) {
             const int x = xi[t * B + colc];
             if (x >= 0) {
@@ -122,11 +136,12 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
             }
             if (t > 1) {
                 const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * 8 * CNT_STRIDE;
-                if (!wait_arrivals(cp, NB, abortp, l) && l == 0) s_abort = 1;
+                if (!wait_arrivals(cp, NB, epoch, abortp, l) && l == 0) s_abort = 1;
             }
         }
         __syncthreads();
         if (s_abort) return;
+        STAMP_AT(1)
 
         const int off = (int)((((size_t)(t - 1) * B + colc) * N + 16 * (w * NK4W) + 4 * q) * sizeof(float));
         float4 b[NK4W];
@@ -150,6 +165,7 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
 #pragma unroll
         for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
         __syncthreads();
+        STAMP_AT(2)
 
         if (w == 0) {
             float pre[4];
@@ -170,9 +186,11 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
             h4.y = __shfl(hv, 16 + c, 64);
             h4.z = __shfl(hv, 32 + c, 64);
             h4.w = __shfl(hv, 48 + c, 64);
+            STAMP_AT(3)
             if (q == 0 && col < B) st_sc1(h4, rH, (int)((((size_t)t * B + col) * N + 4 * p) * sizeof(float)));
             if (t + 1 < S) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                STAMP_AT(4)
                 if (l == 0)
                     __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * 8 + (p & 7)) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
@@ -190,6 +208,156 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward recurrence, granule hand-off (LSTM_HIP_GRANULE_HANDOFF; measured slower).  Same decomposition and arithmetic as
+// k_fwd_persistent, but h_t travels as 8-byte {tag, value} granules (Guideline 16, recipe R2: the data
+// IS the flag): the producing lane writes ONE aligned 8-byte sc1 store per value and moves on -- no
+// drain, no counter, no flag -- and every consuming wave sweeps the granules of its own K-quarter
+// with 16-byte sc1 loads until every tag equals this step's epoch.  The epoch is
+// epoch_base + t with epoch_base = S * (window serial), so a tag left by an earlier window can never
+// match.  Step 1 reads the carry column from plain memory (it was written before the launch).
+// The plain H (which the time-batched products read) is still written, off the critical path.
+// ------------------------------------------------------------------------------------------------
+template <int NK4W, bool FAST>
+__global__ __launch_bounds__(256) void k_fwd_persistent_g(const float4 *__restrict__ Ufwd, const float *__restrict__ W,
+                                                          const float *__restrict__ bias, float *__restrict__ H,
+                                                          float *__restrict__ C, float *__restrict__ G,
+                                                          unsigned long long *Hg, const int32_t *__restrict__ xi,
+                                                          unsigned *abortp, unsigned epoch_base, int S, int B) {
+    constexpr int N = 64 * NK4W, G4 = 4 * N, nk4 = N / 16;
+    __shared__ float red[4 * 4 * 64];
+    __shared__ int s_abort;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int p = blockIdx.x, g = blockIdx.y;
+    const int q = l >> 4, c = l & 15;
+    const int col = 16 * g + c, colc = col < B ? col : B - 1;
+    const int j = 4 * p + q;
+
+    float4 a[NK4W];
+#pragma unroll
+    for (int i = 0; i < NK4W; i++) a[i] = Ufwd[((size_t)p * nk4 + w * NK4W + i) * 64 + l];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (w == 0) {
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
+        cprev = C[(size_t)colc * N + j];
+    }
+    const __amdgpu_buffer_rsrc_t rG = make_rsrc(Hg, (size_t)S * N * B * 8);
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+
+    for (int t = 1; t < S; t++) {
+        float wx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w == 0) {
+            const int x = xi[t * B + colc];
+            if (x >= 0) {
+#pragma unroll
+                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
+            }
+        }
+        float4 b[NK4W];
+        if (t == 1) {
+            const float *hp = H + (size_t)colc * N + 16 * (w * NK4W) + 4 * q;
+#pragma unroll
+            for (int i = 0; i < NK4W; i++) b[i] = *reinterpret_cast<const float4 *>(hp + 16 * i);
+        } else {
+            const unsigned want = epoch_base + (unsigned)(t - 1);
+            const int off = (int)((((size_t)(t - 1) * B + colc) * N + 16 * (w * NK4W) + 4 * q) * 8);
+            bool ok = false;
+            // phase 1: cheap poll -- only the first k-step of this wave's quarter (2 loads per lane,
+            // granules of 4 producers) until it carries this step's tag; a full 16 KB sweep per poll
+            // iteration by every wave of the chip starves the payload traffic it is waiting for
+            int spins = 0;
+            for (; spins <= SPIN_LIMIT; spins++) {
+                asm volatile("" ::: "memory");
+                const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rG, off, 0, 16);
+                const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rG, off + 16, 0, 16);
+                const bool good = v0.y == want && v0.w == want && v1.y == want && v1.w == want;
+                if (__all(good)) break;
+                if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    spins = SPIN_LIMIT + 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            // phase 2: full sweep, every tag checked; repeated only if some producer is later than the polled ones
+            for (; spins <= SPIN_LIMIT; spins++) {
+                asm volatile("" ::: "memory"); // every sweep re-reads memory (no hoisting of the loads)
+                bool good = true;
+#pragma unroll
+                for (int i = 0; i < NK4W; i++) {
+                    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rG, off + 128 * i, 0, 16);
+                    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rG, off + 128 * i + 16, 0, 16);
+                    good = good && v0.y == want && v0.w == want && v1.y == want && v1.w == want;
+                    b[i].x = __uint_as_float(v0.x);
+                    b[i].y = __uint_as_float(v0.z);
+                    b[i].z = __uint_as_float(v1.x);
+                    b[i].w = __uint_as_float(v1.z);
+                }
+                if (__all(good)) {
+                    ok = true;
+                    break;
+                }
+                if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok && l == 0) {
+                __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_abort = 1;
+            }
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NK4W; i++) {
+            if (i & 1) {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc1, 0, 0, 0);
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
+        __syncthreads();
+        if (s_abort) return;
+
+        if (w == 0) {
+            float pre[4];
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) {
+                const float uh = ((red[(0 * 4 + gt) * 64 + l] + red[(1 * 4 + gt) * 64 + l]) + red[(2 * 4 + gt) * 64 + l]) +
+                                 red[(3 * 4 + gt) * 64 + l];
+                pre[gt] = (wx[gt] + uh) + bs[gt]; // R/lstm.cc:176
+            }
+            const float ig = p_sigm<FAST>(pre[0]), og = p_sigm<FAST>(pre[1]), fg = p_sigm<FAST>(pre[2]); // :179
+            const float ug = p_tanh<FAST>(pre[3]);                                                        // :182
+            const float cv = p_tanh<FAST>(ig * ug + fg * cprev);                                          // :185-189
+            const float hv = og * cv;                                                                     // :192
+            cprev = cv;
+            if (col < B) {
+                if (t + 1 < S) { // publish: ONE aligned 8-byte {value, tag} store, nothing to wait for
+                    const unsigned long long gran =
+                        ((unsigned long long)(epoch_base + (unsigned)t) << 32) | (unsigned long long)__float_as_uint(hv);
+                    __hip_atomic_store(Hg + ((size_t)t * B + col) * N + j, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                H[((size_t)t * B + col) * N + j] = hv;
+                float *gc = G + ((size_t)t * B + col) * G4 + j;
+                gc[0] = ig;
+                gc[N] = og;
+                gc[2 * N] = fg;
+                gc[3 * N] = ug;
+                C[((size_t)t * B + col) * N + j] = cv;
+            }
+        }
+        __syncthreads(); // red is rewritten by the next step
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward recurrence, t = S-1..1, N = 32*NR4W.  grid (N/16, ceil(B/16)), 512 threads.
 // Workgroup (kb, g) owns hidden units 16kb..16kb+15 for column group g: one 16x16 tile of
 // dhnext = U^T * dg[t+1] (R/lstm.cc:255) with K = 4N split over its 8 waves (U^T A-fragments in
@@ -199,7 +367,7 @@ template <int NR4W>
 __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict__ Ubwd, float *DG,
                                                         const float *__restrict__ DHy, const float *__restrict__ G,
                                                         const float *__restrict__ C, unsigned *cnt, unsigned *abortp,
-                                                        int S, int B) {
+                                                        unsigned epoch, int S, int B, int stagger) {
     constexpr int N = 32 * NR4W, G4 = 4 * N, nr4 = N / 4;
     __shared__ float red[8 * 4 * 64];
     __shared__ __attribute__((aligned(16))) float stage[16 * 4 * 16];
@@ -222,6 +390,7 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
     float dcn = 0.0f; // dcnext, R/lstm.cc:217
     if (tid == 0) s_abort = 0;
     __syncthreads();
+    for (int i = 0; i < g * stagger; i++) __builtin_amdgcn_s_sleep(32); // see k_fwd_persistent
 
     for (int t = S - 1; t >= 1; t--) {
         // operands of the elementwise part do not depend on the chain: fetch them first
@@ -239,7 +408,7 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
         const bool has_next = t < S - 1;
         if (has_next && w == 0) {
             const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * 8 * CNT_STRIDE;
-            if (!wait_arrivals(cpn, NBK, abortp, l) && l == 0) s_abort = 1;
+            if (!wait_arrivals(cpn, NBK, epoch, abortp, l) && l == 0) s_abort = 1;
         }
         __syncthreads();
         if (s_abort) return;
@@ -349,13 +518,34 @@ bool persistent_supported(int N, int B, int n_cus) {
 }
 
 void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
-                    const int32_t *xi, unsigned *cnt, unsigned *abortp, int N, int S, int B, bool fast, hipStream_t st) {
+                    const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B, bool fast,
+                    hipStream_t st, unsigned long long *stamps) {
     const dim3 grid(N / 4, (B + 15) / 16), block(256);
+    static const int stagger = getenv("LSTM_HIP_FWD_STAGGER") ? atoi(getenv("LSTM_HIP_FWD_STAGGER")) : 0;
+    if (stamps != nullptr && N == 512) { // diagnostic build of the headline shape
+        hipLaunchKernelGGL((k_fwd_persistent<8, false, true>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B, stagger, stamps);
+        return;
+    }
     switch (N / 64) {
 #define X(k)                                                                                                          \
     case k:                                                                                                           \
-        if (fast) hipLaunchKernelGGL((k_fwd_persistent<k, true>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, S, B); \
-        else hipLaunchKernelGGL((k_fwd_persistent<k, false>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, S, B);    \
+        if (fast) hipLaunchKernelGGL((k_fwd_persistent<k, true>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B, stagger, nullptr); \
+        else hipLaunchKernelGGL((k_fwd_persistent<k, false>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B, stagger, nullptr);    \
+        break;
+        FWD_CASES(X)
+#undef X
+    }
+}
+
+void fwd_persistent_granules(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
+                              unsigned long long *Hg, const int32_t *xi, unsigned *abortp, unsigned epoch_base, int N,
+                              int S, int B, bool fast, hipStream_t st) {
+    const dim3 grid(N / 4, (B + 15) / 16), block(256);
+    switch (N / 64) {
+#define X(k)                                                                                                           \
+    case k:                                                                                                            \
+        if (fast) hipLaunchKernelGGL((k_fwd_persistent_g<k, true>), grid, block, 0, st, Ufwd, W, bias, H, C, G, Hg, xi, abortp, epoch_base, S, B); \
+        else hipLaunchKernelGGL((k_fwd_persistent_g<k, false>), grid, block, 0, st, Ufwd, W, bias, H, C, G, Hg, xi, abortp, epoch_base, S, B);    \
         break;
         FWD_CASES(X)
 #undef X
@@ -363,12 +553,13 @@ void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float
 }
 
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, unsigned *cnt,
-                    unsigned *abortp, int N, int S, int B, hipStream_t st) {
+                    unsigned *abortp, unsigned epoch, int N, int S, int B, hipStream_t st) {
     const dim3 grid(N / 16, (B + 15) / 16), block(512);
+    static const int stagger = getenv("LSTM_HIP_BWD_STAGGER") ? atoi(getenv("LSTM_HIP_BWD_STAGGER")) : 0;
     switch (N / 32) {
 #define X(k)                                                                                              \
     case k:                                                                                               \
-        hipLaunchKernelGGL((k_bwd_persistent<k>), grid, block, 0, st, Ubwd, DG, DHy, G, C, cnt, abortp, S, B); \
+        hipLaunchKernelGGL((k_bwd_persistent<k>), grid, block, 0, st, Ubwd, DG, DHy, G, C, cnt, abortp, epoch, S, B, stagger); \
         break;
         BWD_CASES(X)
 #undef X

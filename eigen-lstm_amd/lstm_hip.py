@@ -20,6 +20,8 @@ LIB_PATH = os.path.join(HERE, "liblstm_hip.so")
 FAST_MATH = 1
 NO_GRAPH = 2
 STEP_KERNELS = 4
+GRANULE_HANDOFF = 8
+DEBUG_STAMPS = 16
 UNIQUE_ID_BYTES = 128
 VOCAB = 256
 
@@ -46,7 +48,7 @@ SYMBOLS = [
     "lstm_hip_set_text", "lstm_hip_set_cursors", "lstm_hip_get_cursors", "lstm_hip_reset_window",
     "lstm_hip_get_window", "lstm_hip_train_windows", "lstm_hip_set_global_batch", "lstm_hip_eval_bits",
     "lstm_hip_sample", "lstm_hip_synchronize", "lstm_hip_set_profiling", "lstm_hip_kernel_stat_count",
-    "lstm_hip_kernel_stat", "lstm_hip_reset_kernel_stats", "lstm_hip_device_info",
+    "lstm_hip_kernel_stat", "lstm_hip_reset_kernel_stats", "lstm_hip_device_info", "lstm_hip_debug_stamps",
 ]
 
 
@@ -238,6 +240,11 @@ class Lstm:
         _chk(self.lib.lstm_hip_sample(self._h, _ptr(h0), _ptr(c0), _ptr(u, C.c_double), int(u.size),
                                       _ptr(out, C.c_uint8)))
         return out, h0, c0
+
+    def debug_stamps(self):
+        out = np.zeros((2, self.S, 8), np.uint64)
+        _chk(self.lib.lstm_hip_debug_stamps(self._h, _ptr(out, C.c_uint64), C.c_size_t(out.size)))
+        return out
 
     # ---- measurement ---------------------------------------------------------------------------
     def synchronize(self):

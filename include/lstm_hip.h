@@ -47,6 +47,11 @@ extern "C" {
 #define LSTM_HIP_NO_GRAPH 2u       /* launch kernels eagerly instead of replaying a captured hipGraph */
 #define LSTM_HIP_STEP_KERNELS 4u   /* one launch per timestep (baseline engine) instead of the persistent
                                       recurrence kernels */
+#define LSTM_HIP_GRANULE_HANDOFF 8u /* forward hand-off by 8-byte {value, tag} granules instead of the default sc1
+                                      payload + sharded counters (measured 1.6-1.9x slower; kept for A/B runs) */
+
+#define LSTM_HIP_DEBUG_STAMPS 16u    /* diagnostic build of the forward recurrence (N = 512) that records
+                                      s_memtime at five points of every step; see lstm_hip_debug_stamps */
 
 typedef struct lstm_hip_ctx lstm_hip_t; /* opaque: cuParameters p,d,m + cuLSTM<S> in one object */
 
@@ -131,6 +136,8 @@ int lstm_hip_sample(lstm_hip_t *h, float *h0, float *c0, const double *u, int32_
 /* ---- measurement.  With profiling on, every kernel launch is bracketed by HIP events on the
  *      handle's stream (the graph path is bypassed) and per-kernel totals accumulate. */
 int lstm_hip_synchronize(lstm_hip_t *h);
+/* [2 workgroups][S][8] shader-clock stamps of the last forward (LSTM_HIP_DEBUG_STAMPS handles only) */
+int lstm_hip_debug_stamps(lstm_hip_t *h, uint64_t *out, size_t count);
 int lstm_hip_set_profiling(lstm_hip_t *h, int32_t on);
 int lstm_hip_kernel_stat_count(lstm_hip_t *h);
 int lstm_hip_kernel_stat(lstm_hip_t *h, int32_t idx, const char **name, int64_t *launches, double *total_ms);
