@@ -48,8 +48,13 @@ void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float
 void fwd_persistent_granules(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
                               unsigned long long *Hg, const int32_t *xi, unsigned *abortp, unsigned epoch_base, int N,
                               int S, int B, bool fast, hipStream_t st);
+// follower support: a 1-wave kernel that returns once step `t` of launch `epoch` has been published by all
+// `n_prod` producers of every column group (or the abort word is set)
+void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, unsigned *abortp, hipStream_t st);
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, unsigned *cnt,
-                    unsigned *abortp, unsigned epoch, int N, int S, int B, hipStream_t st);
+                    unsigned *abortp, unsigned epoch, int N, int S, int B, int cols, hipStream_t st,
+                    unsigned long long *stamps = nullptr);
+int bwd_group_cols(int N, int B, int n_cus); // 8 or 16 batch columns per backward workgroup
 
 // ---- time-batched dense products (fp32 MFMA 32x32x2, LDS tiled) ------------------------------
 // C[M x Nn] = op(A)[M x K] * op(B)[K x Nn], column-major; TA: A is stored K x M; TB: B is stored Nn x K.
@@ -58,12 +63,18 @@ void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float
 void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
           int splits, float *slabs, hipStream_t st);
 int gemm_pick_splits(int M, int Nn, int K);
+// one K-slice of a split-K product into slab z / the ordered fold of all slabs (time-chunked overlap)
+void gemm_slice(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *slabs,
+                int kchunk, int z, hipStream_t st);
+void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st);
 
 // ---- output layer elementwise: probs = exp(y+by)/sum ; loss ; dy = probs - onehot  (R/lstm.cc:195-207,225)
 // Y is [T cols][256] (column-major 256 x T) and is overwritten by dY; probs written to P.
 // colloss[col] = -log2 p[target] (0 for an empty target); dby_part[wave][256] partial row sums of dY.
-void softmax_loss_dy(float *Y, float *P, const float *by, const int32_t *ti, float *colloss, float *dby_part, int T,
-                     int *n_parts_out, hipStream_t st);
+// Processes columns [col0, col1) (col0 a multiple of 8) with global indexing, so a window can be done in time chunks.
+int softmax_parts(int T);
+void softmax_loss_dy(float *Y, float *P, const float *by, const int32_t *ti, float *colloss, float *dby_part, int col0,
+                     int col1, hipStream_t st);
 // window loss as the reference sums it: for each t a float sum over b, / B_global, accumulated in double;
 // when dby != null a second workgroup folds the per-wave partials into dby = rowsum(dY) (R/lstm.cc:227)
 void loss_reduce(const float *colloss, int steps, int B, int B_global, double *out, const float *dby_part, int n_parts,
@@ -77,6 +88,9 @@ constexpr int DW_CHUNK = 32;
 size_t dW_scratch_bytes(int T, int G4);
 void dW_db(const float *DG /*[T][G4]*/, const int32_t *xi /*[T]*/, int T, int G4, float *dW /*[256][G4]*/, float *db,
            void *scratch, hipStream_t st);
+// the same in two parts: the sort needs only the input bytes, the sums need the complete DG
+void dW_sort(const int32_t *xi, int T, int G4, void *scratch, hipStream_t st);
+void dW_sums(const float *DG, int T, int G4, float *dW, float *db, void *scratch, hipStream_t st);
 
 // ---- Adagrad over the flat block (R/lstm.cc:261-272; eps added in double, :25,46-48)
 // When Ufwd/Ubwd are given, the U block also refreshes both MFMA fragment images (fused pack_U).

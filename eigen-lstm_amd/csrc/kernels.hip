@@ -338,16 +338,16 @@ template <bool TRANS, int ROWS> __device__ __forceinline__ void gemm_store(float
 template <bool TA, bool TB, int NI>
 __global__ __launch_bounds__(256) void k_gemm(int M, int Nn, int K, const float *__restrict__ A, int lda,
                                               const float *__restrict__ Bm, int ldb, float *__restrict__ C, int ldc,
-                                              int kchunk, size_t slab_stride) {
+                                              int kchunk, size_t slab_stride, int z0) {
     constexpr int GBN = 64 * NI;
     __shared__ __attribute__((aligned(16))) float As[GBK * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[GBK * GLD];
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1;
     const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
-    const int kbeg = blockIdx.z * kchunk;
+    const int kbeg = (blockIdx.z + z0) * kchunk;
     const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
-    C += (size_t)blockIdx.z * slab_stride;
+    C += (size_t)(blockIdx.z + z0) * slab_stride;
 
     f32x16 acc[2][NI];
 #pragma unroll
@@ -427,19 +427,12 @@ int gemm_pick_splits(int M, int Nn, int K) {
     return splits;
 }
 
-void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
-          int splits, float *slabs, hipStream_t st) {
-    if (splits < 1) splits = 1;
-    int kchunk = (K + splits - 1) / splits;
-    kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
-    splits = (K + kchunk - 1) / kchunk;
+static void gemm_launch(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb,
+                        float *out, int ldo, int kchunk, size_t stride, int z0, int nz, hipStream_t st) {
     const int bn = gemm_pick_bn(M, Nn, K);
-    dim3 grid((M + GBM - 1) / GBM, (Nn + bn - 1) / bn, splits);
-    float *out = splits > 1 ? slabs : C;
-    const int ldo = splits > 1 ? M : ldc;
-    const size_t stride = splits > 1 ? (size_t)M * Nn : 0;
+    dim3 grid((M + GBM - 1) / GBM, (Nn + bn - 1) / bn, nz);
 #define GEMM_LAUNCH(ta, tb, ni) \
-    hipLaunchKernelGGL((k_gemm<ta, tb, ni>), grid, dim3(256), 0, st, M, Nn, K, A, lda, B, ldb, out, ldo, kchunk, stride)
+    hipLaunchKernelGGL((k_gemm<ta, tb, ni>), grid, dim3(256), 0, st, M, Nn, K, A, lda, B, ldb, out, ldo, kchunk, stride, z0)
 #define GEMM_NI(ta, tb)              \
     do {                             \
         if (bn == 128) GEMM_LAUNCH(ta, tb, 2); \
@@ -451,12 +444,35 @@ void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const
     else GEMM_NI(true, true);
 #undef GEMM_NI
 #undef GEMM_LAUNCH
-    if (splits > 1) {
-        size_t total = (size_t)M * Nn;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_gemm_reduce, dim3(blocks), dim3(256), 0, st, slabs, splits, M, Nn, C, ldc);
-    }
+}
+static void gemm_reduce_launch(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st) {
+    size_t total = (size_t)M * Nn;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_gemm_reduce, dim3(blocks), dim3(256), 0, st, slabs, splits, M, Nn, C, ldc);
+}
+
+void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+          int splits, float *slabs, hipStream_t st) {
+    if (splits < 1) splits = 1;
+    int kchunk = (K + splits - 1) / splits;
+    kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
+    splits = (K + kchunk - 1) / kchunk;
+    float *out = splits > 1 ? slabs : C;
+    const int ldo = splits > 1 ? M : ldc;
+    const size_t stride = splits > 1 ? (size_t)M * Nn : 0;
+    gemm_launch(TA, TB, M, Nn, K, A, lda, B, ldb, out, ldo, kchunk, stride, 0, splits, st);
+    if (splits > 1) gemm_reduce_launch(slabs, splits, M, Nn, C, ldc, st);
+}
+
+// One K-slice [z*kchunk, (z+1)*kchunk) of a split-K product into slab z (kchunk a multiple of 16); the
+// caller launches the slices as their inputs become available and folds them with gemm_fold.
+void gemm_slice(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *slabs,
+                int kchunk, int z, hipStream_t st) {
+    gemm_launch(TA, TB, M, Nn, K, A, lda, B, ldb, slabs, M, kchunk, (size_t)M * Nn, z, 1, st);
+}
+void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st) {
+    gemm_reduce_launch(slabs, splits, M, Nn, C, ldc, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,9 +485,9 @@ constexpr int SM_COLS_PER_WAVE = 8;
 __global__ __launch_bounds__(256) void k_softmax_loss_dy(float *__restrict__ Y, float *__restrict__ P,
                                                          const float *__restrict__ by, const int32_t *__restrict__ ti,
                                                          float *__restrict__ colloss, float *__restrict__ dby_part,
-                                                         int T) {
+                                                         int col0, int T) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int gw = blockIdx.x * 4 + w;
+    const int gw = col0 / SM_COLS_PER_WAVE + blockIdx.x * 4 + w; // global wave index: columns 8*gw .. 8*gw+7
     const float4 b4 = reinterpret_cast<const float4 *>(by)[l];
     float4 dsum = {0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < SM_COLS_PER_WAVE; q++) {
@@ -511,12 +527,14 @@ __global__ __launch_bounds__(256) void k_softmax_loss_dy(float *__restrict__ Y, 
     }
     reinterpret_cast<float4 *>(dby_part + (size_t)gw * 256)[l] = dsum;
 }
-void softmax_loss_dy(float *Y, float *P, const float *by, const int32_t *ti, float *colloss, float *dby_part, int T,
-                     int *n_parts_out, hipStream_t st) {
-    const int waves = (T + SM_COLS_PER_WAVE - 1) / SM_COLS_PER_WAVE;
+// columns [col0, col1) of a T-column problem; col0 must be a multiple of 8.  dby_part needs
+// softmax_parts(T) rows of 256 floats; rows of waves past col1 are written as zeros.
+int softmax_parts(int T) { return ((T + SM_COLS_PER_WAVE - 1) / SM_COLS_PER_WAVE + 3) / 4 * 4 + 4; }
+void softmax_loss_dy(float *Y, float *P, const float *by, const int32_t *ti, float *colloss, float *dby_part, int col0,
+                     int col1, hipStream_t st) {
+    const int waves = (col1 - col0 + SM_COLS_PER_WAVE - 1) / SM_COLS_PER_WAVE;
     const int blocks = (waves + 3) / 4;
-    *n_parts_out = blocks * 4;
-    hipLaunchKernelGGL(k_softmax_loss_dy, dim3(blocks), dim3(256), 0, st, Y, P, by, ti, colloss, dby_part, T);
+    hipLaunchKernelGGL(k_softmax_loss_dy, dim3(blocks), dim3(256), 0, st, Y, P, by, ti, colloss, dby_part, col0, col1);
 }
 
 // dby = rowsum(dY) (R/lstm.cc:227): fold the per-wave partials.  1024 threads = 64 float4 row groups
@@ -806,16 +824,27 @@ size_t dW_scratch_bytes(int T, int G4) {
     // perm[T] | chunk_start[max_chunks+1] | bucket_chunk[258] | n_chunks[1] | part[max_chunks][G4] | dWnull[G4]
     return sizeof(int32_t) * ((size_t)T + max_chunks + 1 + 258 + 4) + sizeof(float) * (max_chunks * G4 + G4) + 64;
 }
-void dW_db(const float *DG, const int32_t *xi, int T, int G4, float *dW, float *db, void *scratch, hipStream_t st) {
-    const int max_chunks = T / DW_CHUNK + 258;
-    int32_t *perm = reinterpret_cast<int32_t *>(scratch);
-    int32_t *chunk_start = perm + T;
-    int32_t *bucket_chunk = chunk_start + max_chunks + 1;
-    int32_t *n_chunks = bucket_chunk + 258;
-    size_t off = sizeof(int32_t) * ((size_t)T + max_chunks + 1 + 258 + 4);
+struct DwScratch {
+    int32_t *perm, *chunk_start, *bucket_chunk, *n_chunks;
+    float *part, *dWnull;
+    int max_chunks;
+};
+static DwScratch dw_carve(void *scratch, int T, int G4) {
+    DwScratch d;
+    d.max_chunks = T / DW_CHUNK + 258;
+    d.perm = reinterpret_cast<int32_t *>(scratch);
+    d.chunk_start = d.perm + T;
+    d.bucket_chunk = d.chunk_start + d.max_chunks + 1;
+    d.n_chunks = d.bucket_chunk + 258;
+    size_t off = sizeof(int32_t) * ((size_t)T + d.max_chunks + 1 + 258 + 4);
     off = (off + 63) & ~(size_t)63;
-    float *part = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + off);
-    float *dWnull = part + (size_t)max_chunks * G4;
+    d.part = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + off);
+    d.dWnull = d.part + (size_t)d.max_chunks * G4;
+    return d;
+}
+// pass 1: depends only on the window's input bytes, so it can run beside the backward recurrence
+void dW_sort(const int32_t *xi, int T, int G4, void *scratch, hipStream_t st) {
+    const DwScratch d = dw_carve(scratch, T, G4);
     if (T <= 64 * 16 * RANK_SLOTS) {
         const size_t lds = (size_t)((T + 63) / 64) * 257 * sizeof(unsigned short);
         static bool attr_set = false;
@@ -824,15 +853,25 @@ void dW_db(const float *DG, const int32_t *xi, int T, int G4, float *dW, float *
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_bucket_columns_rank, dim3(1), dim3(1024), lds, st, xi, T, perm, chunk_start, bucket_chunk,
-                           n_chunks);
+        hipLaunchKernelGGL(k_bucket_columns_rank, dim3(1), dim3(1024), lds, st, xi, T, d.perm, d.chunk_start,
+                           d.bucket_chunk, d.n_chunks);
     } else {
-        hipLaunchKernelGGL(k_bucket_columns, dim3(1), dim3(1024), 0, st, xi, T, perm, chunk_start, bucket_chunk, n_chunks);
+        hipLaunchKernelGGL(k_bucket_columns, dim3(1), dim3(1024), 0, st, xi, T, d.perm, d.chunk_start, d.bucket_chunk,
+                           d.n_chunks);
     }
-    hipLaunchKernelGGL(k_dW_segsum, dim3(max_chunks), dim3(256), 0, st, DG, G4, perm, chunk_start, bucket_chunk, n_chunks,
-                       part);
-    hipLaunchKernelGGL(k_dW_finish, dim3(257, (G4 / 4 + 255) / 256), dim3(256), 0, st, part, bucket_chunk, G4, dW, dWnull);
-    hipLaunchKernelGGL(k_db_finish, dim3((G4 + 63) / 64), dim3(256), 0, st, dW, dWnull, G4, db);
+}
+// passes 2-4: need the complete DG
+void dW_sums(const float *DG, int T, int G4, float *dW, float *db, void *scratch, hipStream_t st) {
+    const DwScratch d = dw_carve(scratch, T, G4);
+    hipLaunchKernelGGL(k_dW_segsum, dim3(d.max_chunks), dim3(256), 0, st, DG, G4, d.perm, d.chunk_start, d.bucket_chunk,
+                       d.n_chunks, d.part);
+    hipLaunchKernelGGL(k_dW_finish, dim3(257, (G4 / 4 + 255) / 256), dim3(256), 0, st, d.part, d.bucket_chunk, G4, dW,
+                       d.dWnull);
+    hipLaunchKernelGGL(k_db_finish, dim3((G4 + 63) / 64), dim3(256), 0, st, dW, d.dWnull, G4, db);
+}
+void dW_db(const float *DG, const int32_t *xi, int T, int G4, float *dW, float *db, void *scratch, hipStream_t st) {
+    dW_sort(xi, T, G4, scratch, st);
+    dW_sums(DG, T, G4, dW, db, scratch, st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -82,8 +82,17 @@ struct lstm_hip_ctx {
     lstm_hip_config cfg{};
     ParamLayout pl{};
     int T = 0; // (S-1)*B columns in the time-batched matrices
-    hipStream_t st = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t st = nullptr, st2 = nullptr; // st2: followers of the persistent recurrences (overlap mode)
+    hipStream_t st_b = nullptr;              // backward recurrence on one half of the CUs while st2 uses the other half
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_main = nullptr, ev_join = nullptr;
+    bool overlap = false;
+    int overlap_mask = 0;      // 1: forward followers, 2: backward followers, 4: CU-partitioned streams.  Measured
+                               // slower than serial in every combination, so off unless
+                               // LSTM_HIP_OVERLAP_MASK is set
+    int chunk_steps = 0;       // timesteps per follower chunk
+    float *slabs_dU = nullptr; // split-K slabs of dU (one per time chunk in overlap mode)
+    bool dhy_done = false;
+    int bwd_cols = 16;         // batch columns per backward-recurrence workgroup (8 or 16)
 
     float *P = nullptr, *dP = nullptr, *mem = nullptr;
     float4 *Ufwd = nullptr, *Ubwd = nullptr;
@@ -181,6 +190,48 @@ int check_abort(lstm_hip_ctx *h) {
     return 0;
 }
 
+// Overlap mode: while a persistent recurrence runs on `st`, the time-batched work that only needs the
+// steps already finished runs on `st2` behind k_wait_progress (forward: Y, softmax/loss/dY, DHy per
+// time chunk; backward: dWhy, the dW bucket sort, and dU one K-slice per time chunk).  Both streams
+// are joined before the function returns, so callers only ever see `st`.
+bool overlap_now(const lstm_hip_ctx *h, int which /*1 fwd, 2 bwd*/) { return h->overlap && !h->profiling && (h->overlap_mask & which); }
+
+int launch_fwd_recurrence(lstm_hip_ctx *h) {
+    const int N = h->cfg.N, B = h->cfg.B, S = h->cfg.S;
+    const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
+    if (!(h->cfg.flags & LSTM_HIP_GRANULE_HANDOFF)) {
+        if (h->fwd_epoch >= (1u << 26)) { // keep epoch * arrivals inside 32 bits
+            HIP_TRY(hipMemsetAsync(h->cnt, 0, h->cnt_bytes, h->st));
+            h->fwd_epoch = 0;
+        }
+        h->fwd_epoch++;
+        RUN(K_FWD_PERSIST, fwd_persistent(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->cnt,
+                                          h->abortp, h->fwd_epoch, N, S, B, fast, h->st, h->stamps));
+    } else {
+        h->window_serial++;
+        if ((unsigned long long)(h->window_serial + 1) * (unsigned)S >= 0xffffffffull) { // tag space exhausted: start over
+            HIP_TRY(hipMemsetAsync(h->Hg, 0, sizeof(unsigned long long) * (size_t)S * B * N, h->st));
+            h->window_serial = 1;
+        }
+        RUN(K_FWD_PERSIST, fwd_persistent_granules(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->Hg, h->xi,
+                                                   h->abortp, h->window_serial * (unsigned)S, N, S, B, fast, h->st));
+    }
+    return 0;
+}
+
+// output layer for the columns of steps [ta, tb] on stream s: Y = Why*h (R/lstm.cc:195), softmax/loss/dy
+// (:199-207,225), and DHy = Why^T*dy (:228)
+void output_layer_chunk(lstm_hip_ctx *h, int ta, int tb, hipStream_t s) {
+    const int N = h->cfg.N, B = h->cfg.B;
+    const int col0 = (ta - 1) * B, col1 = tb * B, nc = col1 - col0;
+    float *Y1 = h->Y + (size_t)256 * B;
+    gemm(false, false, 256, nc, N, h->P + h->pl.Why, 256, h->H + (size_t)N * B + (size_t)col0 * N, N,
+         Y1 + (size_t)col0 * 256, 256, 1, nullptr, s);
+    softmax_loss_dy(Y1, h->Pr + (size_t)256 * B, h->P + h->pl.by, h->ti + B, h->colloss, h->dby_part, col0, col1, s);
+    gemm(true, false, N, nc, 256, h->P + h->pl.Why, 256, Y1 + (size_t)col0 * 256, 256,
+         h->DHy + (size_t)N * B + (size_t)col0 * N, N, 1, nullptr, s);
+}
+
 int do_forward(lstm_hip_ctx *h) {
     const int N = h->cfg.N, B = h->cfg.B, S = h->cfg.S, G4 = 4 * N;
     const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
@@ -188,36 +239,42 @@ int do_forward(lstm_hip_ctx *h) {
         RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd, h->Ubwd, N, h->st));
         h->packed = true;
     }
-    if (h->persistent) {
-        if (!(h->cfg.flags & LSTM_HIP_GRANULE_HANDOFF)) {
-            if (h->fwd_epoch >= (1u << 26)) { // keep epoch * arrivals inside 32 bits
-                HIP_TRY(hipMemsetAsync(h->cnt, 0, h->cnt_bytes, h->st));
-                h->fwd_epoch = 0;
-            }
-            h->fwd_epoch++;
-            RUN(K_FWD_PERSIST, fwd_persistent(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->cnt,
-                                              h->abortp, h->fwd_epoch, N, S, B, fast, h->st, h->stamps));
-        } else {
-            h->window_serial++;
-            if ((unsigned long long)(h->window_serial + 1) * (unsigned)S >= 0xffffffffull) { // tag space exhausted: start over
-                HIP_TRY(hipMemsetAsync(h->Hg, 0, sizeof(unsigned long long) * (size_t)S * B * N, h->st));
-                h->window_serial = 1;
-            }
-            RUN(K_FWD_PERSIST, fwd_persistent_granules(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->Hg,
-                                                       h->xi, h->abortp, h->window_serial * (unsigned)S, N, S, B, fast,
-                                                       h->st));
+    h->n_dby_parts = softmax_parts(h->T);
+    h->dhy_done = false;
+    if (h->persistent && overlap_now(h, 1)) {
+        const int NG = (B + 15) / 16;
+        HIP_TRY(hipEventRecord(h->ev_fork, h->st));
+        HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+        int rc = launch_fwd_recurrence(h);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(h->ev_main, h->st));
+        for (int ta = 1; ta < S; ta += h->chunk_steps) {
+            const int tb = ta + h->chunk_steps - 1 < S - 1 ? ta + h->chunk_steps - 1 : S - 1;
+            if (tb <= S - 2) wait_progress(h->cnt, tb, NG, N / 4, h->fwd_epoch, h->abortp, h->st2);
+            else HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_main, 0)); // the last step publishes nothing: wait for the launch
+            output_layer_chunk(h, ta, tb, h->st2);
         }
-    } else
-    for (int t = 1; t < S; t++) {
-        RUN(K_FWD_STEP, fwd_step(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H + (size_t)(t - 1) * N * B,
-                                 h->C + (size_t)(t - 1) * N * B, h->H + (size_t)t * N * B, h->C + (size_t)t * N * B,
-                                 h->G + (size_t)t * G4 * B, h->xi + (size_t)t * B, N, B, fast, h->st));
+        HIP_TRY(hipEventRecord(h->ev_join, h->st2));
+        HIP_TRY(hipStreamWaitEvent(h->st, h->ev_join, 0));
+        h->dhy_done = true;
+        h->fwd_done = true;
+        return 0;
+    }
+    if (h->persistent) {
+        int rc = launch_fwd_recurrence(h);
+        if (rc) return rc;
+    } else {
+        for (int t = 1; t < S; t++) {
+            RUN(K_FWD_STEP, fwd_step(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H + (size_t)(t - 1) * N * B,
+                                     h->C + (size_t)(t - 1) * N * B, h->H + (size_t)t * N * B, h->C + (size_t)t * N * B,
+                                     h->G + (size_t)t * G4 * B, h->xi + (size_t)t * B, N, B, fast, h->st));
+        }
     }
     // Y = Why * H[1..S-1]   (R/lstm.cc:195 for every step at once)
     RUN(K_GEMM_Y, gemm(false, false, 256, h->T, N, h->P + h->pl.Why, 256, h->H + (size_t)N * B, N,
                        h->Y + (size_t)256 * B, 256, 1, nullptr, h->st));
     RUN(K_SOFTMAX, softmax_loss_dy(h->Y + (size_t)256 * B, h->Pr + (size_t)256 * B, h->P + h->pl.by, h->ti + B,
-                                   h->colloss, h->dby_part, h->T, &h->n_dby_parts, h->st));
+                                   h->colloss, h->dby_part, 0, h->T, h->st));
     h->fwd_done = true;
     return 0;
 }
@@ -231,31 +288,66 @@ int do_backward(lstm_hip_ctx *h) {
         RUN(K_DBY, loss_reduce(h->colloss, S - 1, B, h->global_B, h->d_loss, h->dby_part, h->n_dby_parts,
                                h->dP + h->pl.by, h->st));
     h->dby_done = false;
-    // DHy = Why^T * dY                 R/lstm.cc:228, all steps
-    RUN(K_GEMM_DHY, gemm(true, false, N, T, 256, h->P + h->pl.Why, 256, dY, 256, h->DHy + (size_t)N * B, N, 1, nullptr,
-                         h->st));
+    // DHy = Why^T * dY                 R/lstm.cc:228, all steps (already done by the forward's followers in overlap mode)
+    if (!h->dhy_done)
+        RUN(K_GEMM_DHY, gemm(true, false, N, T, 256, h->P + h->pl.Why, 256, dY, 256, h->DHy + (size_t)N * B, N, 1, nullptr,
+                             h->st));
+    h->dhy_done = false;
+    unsigned *cb = h->cnt + h->cnt_bytes / sizeof(unsigned);
     if (h->persistent) {
-        unsigned *cb = h->cnt + h->cnt_bytes / sizeof(unsigned);
         if (h->bwd_epoch >= (1u << 26)) {
             HIP_TRY(hipMemsetAsync(cb, 0, h->cnt_bytes, h->st));
             h->bwd_epoch = 0;
         }
         h->bwd_epoch++;
-        RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, cb, h->abortp, h->bwd_epoch, N, S, B, h->st));
-    } else {
-    HIP_TRY(hipMemsetAsync(h->dcnext, 0, sizeof(float) * N * B, h->st)); // R/lstm.cc:216-217
-    for (int t = S - 1; t >= 1; t--) {
-        RUN(K_BWD_STEP, bwd_step(h->Ubwd, t < S - 1 ? h->DG + (size_t)(t + 1) * G4 * B : nullptr,
-                                 h->DHy + (size_t)t * N * B, h->G + (size_t)t * G4 * B, h->C + (size_t)t * N * B,
-                                 h->C + (size_t)(t - 1) * N * B, h->dcnext, h->DG + (size_t)t * G4 * B, N, B, h->st));
     }
+    if (h->persistent && overlap_now(h, 2)) {
+        hipStream_t sb = h->st_b ? h->st_b : h->st;
+        HIP_TRY(hipEventRecord(h->ev_fork, h->st));
+        HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+        if (h->st_b) HIP_TRY(hipStreamWaitEvent(h->st_b, h->ev_fork, 0));
+        bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, cb, h->abortp, h->bwd_epoch, N, S, B, h->bwd_cols, sb);
+        HIP_TRY(hipEventRecord(h->ev_main, sb));
+        // Followers must not be dispatched before every workgroup of the recurrence has been placed
+        // (otherwise the dispatcher packs recurrence workgroups unevenly around them and the whole
+        // chain runs at the pace of the most crowded CU): the first published step proves that.
+        const int NGb = (B + h->bwd_cols - 1) / h->bwd_cols;
+        if (S - 1 >= 2) wait_progress(cb, S - 1, NGb, N / 16, h->bwd_epoch, h->abortp, h->st2);
+        // independent of the recurrence: dWhy = dY * H^T (R/lstm.cc:226) and the dW bucket sort
+        gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256, h->splits_dWhy, h->slabs,
+             h->st2);
+        dW_sort(h->xi + B, T, G4, h->dw_scratch, h->st2);
+        // dU = DG * H[0..S-2]^T (R/lstm.cc:250), one K-slice per time chunk, latest steps first
+        const int kchunk = h->chunk_steps * B, nz = (S - 1 + h->chunk_steps - 1) / h->chunk_steps;
+        for (int z = nz - 1; z >= 0; z--) {
+            const int ta = z * h->chunk_steps + 1; // earliest step of the slice = last one the recurrence reaches
+            if (ta >= 2) wait_progress(cb, ta, NGb, N / 16, h->bwd_epoch, h->abortp, h->st2);
+            else HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_main, 0)); // step 1 publishes nothing
+            gemm_slice(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->slabs_dU, kchunk, z, h->st2);
+        }
+        gemm_fold(h->slabs_dU, nz, G4, N, h->dP + h->pl.U, G4, h->st2);
+        dW_sums(h->DG + (size_t)G4 * B, T, G4, h->dP + h->pl.W, h->dP + h->pl.b, h->dw_scratch, h->st2);
+        HIP_TRY(hipEventRecord(h->ev_join, h->st2));
+        HIP_TRY(hipStreamWaitEvent(h->st, h->ev_join, 0));
+        return 0;
+    }
+    if (h->persistent) {
+        RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, cb, h->abortp, h->bwd_epoch, N, S, B, h->bwd_cols,
+                                          h->st, h->stamps ? h->stamps + (size_t)2 * S * 8 : nullptr));
+    } else {
+        HIP_TRY(hipMemsetAsync(h->dcnext, 0, sizeof(float) * N * B, h->st)); // R/lstm.cc:216-217
+        for (int t = S - 1; t >= 1; t--) {
+            RUN(K_BWD_STEP, bwd_step(h->Ubwd, t < S - 1 ? h->DG + (size_t)(t + 1) * G4 * B : nullptr,
+                                     h->DHy + (size_t)t * N * B, h->G + (size_t)t * G4 * B, h->C + (size_t)t * N * B,
+                                     h->C + (size_t)(t - 1) * N * B, h->dcnext, h->DG + (size_t)t * G4 * B, N, B, h->st));
+        }
     }
     // dWhy = dY * H[1..]^T             R/lstm.cc:226
     RUN(K_GEMM_DWHY, gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256,
                           h->splits_dWhy, h->slabs, h->st));
     // dU = DG * H[0..S-2]^T            R/lstm.cc:250
     RUN(K_GEMM_DU, gemm(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->dP + h->pl.U, G4, h->splits_dU,
-                        h->slabs, h->st));
+                        h->slabs_dU, h->st));
     // dW, db                           R/lstm.cc:251-252
     RUN(K_DW_DB, dW_db(h->DG + (size_t)G4 * B, h->xi + B, T, G4, h->dP + h->pl.W, h->dP + h->pl.b, h->dw_scratch, h->st));
     return 0;
@@ -332,12 +424,16 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
     ALLOC(h->DHy, N * B * S);
     ALLOC(h->dcnext, N * B);
     ALLOC(h->colloss, B * S);
-    ALLOC(h->dby_part, (size_t)256 * (h->T / 8 + 8));
+    ALLOC(h->dby_part, (size_t)256 * softmax_parts(h->T));
     h->splits_dWhy = gemm_pick_splits(256, (int)N, h->T);
     h->splits_dU = gemm_pick_splits((int)G4, (int)N, h->T);
+    h->chunk_steps = (int)((S - 1 + 8) / 9); // ~9 follower chunks per window
+    if (const char *e = getenv("LSTM_HIP_CHUNK_STEPS")) h->chunk_steps = atoi(e) > 0 ? atoi(e) : h->chunk_steps;
     {
-        size_t a = (size_t)h->splits_dWhy * 256 * N, b = (size_t)h->splits_dU * G4 * N;
-        ALLOC(h->slabs, a > b ? a : b);
+        const size_t nz = (S - 1 + h->chunk_steps - 1) / h->chunk_steps;
+        const size_t want = nz > (size_t)h->splits_dU ? nz : (size_t)h->splits_dU;
+        ALLOC(h->slabs, (size_t)h->splits_dWhy * 256 * N);
+        ALLOC(h->slabs_dU, want * G4 * N);
     }
     ALLOC(h->dw_scratch, dW_scratch_bytes(h->T, (int)G4));
     ALLOC(h->xi, S * B);
@@ -355,8 +451,24 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
     ALLOC(h->cnt, 2 * h->cnt_bytes / sizeof(unsigned));
     ALLOC(h->abortp, 4);
     h->persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) && persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount);
+    h->bwd_cols = bwd_group_cols(cfg->N, cfg->B, prop.multiProcessorCount);
+    // followers need whole MFMA k-tiles and whole softmax waves per time chunk
+    h->overlap = h->persistent && !(cfg->flags & (LSTM_HIP_NO_OVERLAP | LSTM_HIP_GRANULE_HANDOFF)) && cfg->B % 16 == 0;
+    if (const char *e = getenv("LSTM_HIP_OVERLAP_MASK")) h->overlap_mask = atoi(e);
+    if (h->overlap && (h->overlap_mask & 4)) {
+        // CU-partitioned overlap: the backward recurrence (N/16 * ceil(B/16) workgroups, one per CU) gets the
+        // even CUs, its followers the odd ones, so they do not compete for SIMD issue slots or LDS.
+        const int words = (prop.multiProcessorCount + 31) / 32;
+        std::vector<uint32_t> even(words, 0x55555555u), odd(words, 0xaaaaaaaau);
+        HIP_TRY(hipExtStreamCreateWithCUMask(&h->st_b, words, even.data()));
+        HIP_TRY(hipExtStreamCreateWithCUMask(&h->st2, words, odd.data()));
+    } else
+    HIP_TRY(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     if (h->persistent && (cfg->flags & LSTM_HIP_GRANULE_HANDOFF)) ALLOC(h->Hg, S * B * N);
-    if (h->persistent && (cfg->flags & LSTM_HIP_DEBUG_STAMPS)) ALLOC(h->stamps, 2 * S * 8);
+    if (h->persistent && (cfg->flags & LSTM_HIP_DEBUG_STAMPS)) ALLOC(h->stamps, 4 * S * 8);
     HIP_TRY(hipDeviceSynchronize());
     *out = h;
     return 0;
@@ -366,13 +478,18 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->st);
+    if (h->st2) (void)hipStreamSynchronize(h->st2);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
-                    h->colloss, h->dby_part, h->slabs, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->Hg, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
+                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->Hg, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : {h->ev_fork, h->ev_main, h->ev_join})
+        if (e) (void)hipEventDestroy(e);
+    if (h->st2) (void)hipStreamDestroy(h->st2);
+    if (h->st_b) (void)hipStreamDestroy(h->st_b);
     if (h->st) (void)hipStreamDestroy(h->st);
     delete h;
     return 0;
@@ -642,7 +759,7 @@ int lstm_hip_sample(lstm_hip_t *h, float *h0, float *c0, const double *u, int32_
 int lstm_hip_debug_stamps(lstm_hip_t *h, uint64_t *out, size_t count) {
     CHECK(h);
     if (!h->stamps) return fail(LSTM_HIP_ESTATE, "handle was not created with LSTM_HIP_DEBUG_STAMPS on a supported shape");
-    const size_t have = (size_t)2 * h->cfg.S * 8;
+    const size_t have = (size_t)4 * h->cfg.S * 8;
     HIP_TRY(hipMemcpyAsync(out, h->stamps, sizeof(uint64_t) * (count < have ? count : have), hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
     return 0;

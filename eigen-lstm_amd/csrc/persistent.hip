@@ -43,6 +43,14 @@ template <bool FAST> __device__ __forceinline__ float p_tanh(float x) {
     return tanhf(x);
 }
 
+// fragment loads kept in flight ahead of the MFMAs (see the pipelines below); -D overrides for A/B builds
+#ifndef BWD_PF
+#define BWD_PF 6
+#endif
+#ifndef FWD_PF
+#define FWD_PF 4
+#endif
+
 constexpr int CNT_STRIDE = 16;       // uints between shards: one 64-byte line each
 constexpr int SPIN_LIMIT = 1 << 21;  // bounded spin; ~seconds
 
@@ -123,7 +131,8 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
     // Stagger the column groups in time: their recurrences are independent, and every step of a
     // group is a burst of device-scope loads (all its workgroups pull the same h_{t-1}); offsetting
     // group g by g/NG of a step keeps the groups out of each other's burst.
-    for (int i = 0; i < g * stagger; i++) __builtin_amdgcn_s_sleep(32);
+    if (!STAMP)
+        for (int i = 0; i < g * stagger; i++) __builtin_amdgcn_s_sleep(32);
 
     for (int t = 1; t < S; t++) {
         float wx[4] = {0.f, 0.f, 0.f, 0.f};
@@ -144,12 +153,18 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
         STAMP_AT(1)
 
         const int off = (int)((((size_t)(t - 1) * B + colc) * N + 16 * (w * NK4W) + 4 * q) * sizeof(float));
+        // Software pipeline: PF fragment loads in flight ahead of the MFMAs (the scheduler alone keeps two;
+        // see k_bwd_persistent).  Diagnostic builds: `stagger` doubles as "fragments to load".
+        constexpr int PF = FWD_PF < NK4W ? FWD_PF : NK4W;
         float4 b[NK4W];
 #pragma unroll
-        for (int i = 0; i < NK4W; i++) b[i] = ld_sc1(rH, off + 64 * i);
+        for (int i = 0; i < PF; i++) b[i] = (STAMP && i >= stagger) ? float4{0.f, 0.f, 0.f, 0.f} : ld_sc1(rH, off + 64 * i);
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < NK4W; i++) {
+            if (i + PF < NK4W)
+                b[i + PF] = (STAMP && i + PF >= stagger) ? float4{0.f, 0.f, 0.f, 0.f} : ld_sc1(rH, off + 64 * (i + PF));
             if (i & 1) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc1, 0, 0, 0);
@@ -161,6 +176,7 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc0, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc0, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
@@ -363,11 +379,15 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_g(const float4 *__restri
 // dhnext = U^T * dg[t+1] (R/lstm.cc:255) with K = 4N split over its 8 waves (U^T A-fragments in
 // VGPRs), then one thread per (unit, column) does R/lstm.cc:228-247,256 and dg[t] is published.
 // ------------------------------------------------------------------------------------------------
-template <int NR4W>
+#define BSTAMP_AT(k)                                                                     \
+    if (STAMP && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
+        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+template <int NR4W, int COLS, bool STAMP = false>
 __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict__ Ubwd, float *DG,
                                                         const float *__restrict__ DHy, const float *__restrict__ G,
                                                         const float *__restrict__ C, unsigned *cnt, unsigned *abortp,
-                                                        unsigned epoch, int S, int B, int stagger) {
+                                                        unsigned epoch, int S, int B, int stagger,
+                                                        unsigned long long *stamps = nullptr) {
     constexpr int N = 32 * NR4W, G4 = 4 * N, nr4 = N / 4;
     __shared__ float red[8 * 4 * 64];
     __shared__ __attribute__((aligned(16))) float stage[16 * 4 * 16];
@@ -375,13 +395,18 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int kb = blockIdx.x, g = blockIdx.y, NBK = gridDim.x, NG = gridDim.y;
     const int q = l >> 4;
-    const int mcol = 16 * g + (l & 15), mcolc = mcol < B ? mcol : B - 1; // MFMA B-operand column
-    // epilogue role (threads 0..255): unit jj, column cc
-    const int jj = tid & 15, cc = (tid >> 4) & 15;
-    const int ecol = 16 * g + cc, ecolc = ecol < B ? ecol : B - 1;
+    // COLS = 16: the MFMA tile is full.  COLS = 8: lanes 8..15 of the B operand repeat columns 0..7 and
+    // half of the tile is discarded -- the matrix pipe is not what bounds a step; the dg_{t+1} bytes each
+    // CU must pull over the fabric are (K x COLS floats), and 8-column groups halve them per CU while
+    // doubling the number of CUs at work.
+    constexpr int ETH = 16 * COLS; // threads with an elementwise / store role
+    const int mcol = COLS * g + (l & (COLS - 1)), mcolc = mcol < B ? mcol : B - 1; // MFMA B-operand column
+    // epilogue role (threads 0..ETH-1): unit jj, column cc
+    const int jj = tid & 15, cc = (tid >> 4) & (COLS - 1);
+    const int ecol = COLS * g + cc, ecolc = ecol < B ? ecol : B - 1;
     const int j = 16 * kb + jj;
-    // store role (threads 0..255): float4 of 4 consecutive units for (column sc, gate sg)
-    const int sc = (tid >> 4) & 15, sg = (tid >> 2) & 3, sq = tid & 3;
+    // store role (threads 0..ETH-1): float4 of 4 consecutive units for (column sc, gate sg)
+    const int sc = (tid >> 4) & (COLS - 1), sg = (tid >> 2) & 3, sq = tid & 3;
 
     float4 a[NR4W];
 #pragma unroll
@@ -390,12 +415,14 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
     float dcn = 0.0f; // dcnext, R/lstm.cc:217
     if (tid == 0) s_abort = 0;
     __syncthreads();
-    for (int i = 0; i < g * stagger; i++) __builtin_amdgcn_s_sleep(32); // see k_fwd_persistent
+    if (!STAMP)
+        for (int i = 0; i < g * stagger; i++) __builtin_amdgcn_s_sleep(32); // see k_fwd_persistent
 
     for (int t = S - 1; t >= 1; t--) {
+        BSTAMP_AT(0)
         // operands of the elementwise part do not depend on the chain: fetch them first
         float ig = 0.f, og = 0.f, fg = 0.f, ug = 0.f, cv = 0.f, cp = 0.f, dhy = 0.f;
-        if (tid < 256) {
+        if (tid < ETH) {
             const float *gc = G + ((size_t)t * B + ecolc) * G4 + j;
             ig = gc[0];
             og = gc[N];
@@ -412,16 +439,29 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
         }
         __syncthreads();
         if (s_abort) return;
+        BSTAMP_AT(1)
 
         float dhn = 0.0f;
         if (has_next) {
             const int off = (int)((((size_t)(t + 1) * B + mcolc) * G4 + 16 * (w * NR4W) + 4 * q) * sizeof(float));
+            // Software pipeline with PF fragment loads in flight ahead of the MFMAs.  Left to itself the
+            // scheduler keeps only two in flight (a fabric round trip per pair of loads: measured +220
+            // cycles per load), and all NR4W at once measured slower still; sched_barriers pin the order.
+            // COLS = 8: tile columns 8..15 are discarded, so their B operand may be anything -- those lanes
+            // issue no load at all.
+            constexpr int PF = BWD_PF < NR4W ? BWD_PF : NR4W;
+            const bool ld_lane = COLS == 16 || (l & 15) < COLS;
             float4 b[NR4W];
 #pragma unroll
-            for (int i = 0; i < NR4W; i++) b[i] = ld_sc1(rDG, off + 64 * i);
+            for (int i = 0; i < PF; i++)
+                b[i] = (ld_lane && !(STAMP && i >= stagger)) ? ld_sc1(rDG, off + 64 * i) : float4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NR4W; i++) {
+                if (i + PF < NR4W)
+                    b[i + PF] = (ld_lane && !(STAMP && i + PF >= stagger)) ? ld_sc1(rDG, off + 64 * (i + PF))
+                                                                           : float4{0.f, 0.f, 0.f, 0.f};
                 if (i & 1) {
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc1, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc1, 0, 0, 0);
@@ -433,18 +473,20 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc0, 0, 0, 0);
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc0, 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
             __syncthreads();
-            if (tid < 256) {
+            BSTAMP_AT(2)
+            if (tid < ETH) {
                 // D[row = 4*(lane>>4) + reg][col = lane&15]  ->  unit jj lives in lane (jj>>2)*16 + cc, reg jj&3
                 const int src = (jj >> 2) * 16 + cc, reg = jj & 3;
 #pragma unroll
                 for (int ww = 0; ww < 8; ww++) dhn += red[(ww * 4 + reg) * 64 + src];
             }
         }
-        if (tid < 256) {
+        if (tid < ETH) {
             const float dh = dhy + dhn;                         // R/lstm.cc:228
             float dcv = dh * og + dcn;                          // :233
             dcv = dcv * (1.0f - cv * cv);                       // :235
@@ -460,8 +502,9 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
             sp[48] = d_u;
         }
         __syncthreads();
-        if (tid < 256) {
-            const int scol = 16 * g + sc;
+        BSTAMP_AT(3)
+        if (tid < ETH) {
+            const int scol = COLS * g + sc;
             if (scol < B) {
                 const float4 v = *reinterpret_cast<const float4 *>(stage + (sc * 4 + sg) * 16 + 4 * sq);
                 st_sc1(v, rDG, (int)((((size_t)t * B + scol) * G4 + sg * N + 16 * kb + 4 * sq) * sizeof(float)));
@@ -470,6 +513,7 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
         if (t > 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the signal
             __syncthreads();
+            BSTAMP_AT(4)
             if (tid == 0)
                 __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * 8 + (kb & 7)) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
@@ -478,10 +522,24 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_wait_progress: lets work on a second stream follow a running recurrence.  One wave waits until
+// every column group's counters show that step t has been published; kernels queued behind it on the
+// same stream then read data that was written through (sc1) before the counters moved.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch,
+                                                      unsigned *abortp) {
+    for (int g = 0; g < NG; g++)
+        if (!wait_arrivals(cnt + (size_t)(t * NG + g) * 8 * CNT_STRIDE, n_prod, epoch, abortp, threadIdx.x)) return;
+}
+void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, unsigned *abortp, hipStream_t st) {
+    hipLaunchKernelGGL(k_wait_progress, dim3(1), dim3(64), 0, st, cnt, t, NG, n_prod, epoch, abortp);
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 size_t persistent_counter_bytes(int S, int B) {
-    const int NG = (B + 15) / 16;
+    const int NG = (B + 7) / 8; // the backward recurrence may use 8-column groups
     return (size_t)(S + 1) * NG * 8 * CNT_STRIDE * sizeof(unsigned);
 }
 
@@ -505,7 +563,7 @@ bool persistent_supported(int N, int B, int n_cus) {
         default: return false;
     }
     switch (N / 32) {
-#define X(k) case k: bb = blocks_per_cu(k_bwd_persistent<k>, 512); break;
+#define X(k) case k: bb = blocks_per_cu(k_bwd_persistent<k, 16, false>, 512); break;
         BWD_CASES(X)
 #undef X
         default: return false;
@@ -552,14 +610,32 @@ void fwd_persistent_granules(const float4 *Ufwd, const float *W, const float *bi
     }
 }
 
+// 8-column groups when that still fits one workgroup per CU (more CUs pulling fewer bytes each)
+int bwd_group_cols(int N, int B, int n_cus) {
+    static const int force = getenv("LSTM_HIP_BWD_COLS") ? atoi(getenv("LSTM_HIP_BWD_COLS")) : 0;
+    if (force == 8 || force == 16) return force;
+    return (N / 16) * ((B + 7) / 8) <= n_cus && B > 8 ? 8 : 16;
+}
+
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, unsigned *cnt,
-                    unsigned *abortp, unsigned epoch, int N, int S, int B, hipStream_t st) {
-    const dim3 grid(N / 16, (B + 15) / 16), block(512);
+                    unsigned *abortp, unsigned epoch, int N, int S, int B, int cols, hipStream_t st,
+                    unsigned long long *stamps) {
+    const dim3 grid(N / 16, (B + cols - 1) / cols), block(512);
     static const int stagger = getenv("LSTM_HIP_BWD_STAGGER") ? atoi(getenv("LSTM_HIP_BWD_STAGGER")) : 0;
+    if (stamps != nullptr && N == 512) {
+        if (cols == 8)
+            hipLaunchKernelGGL((k_bwd_persistent<16, 8, true>), grid, block, 0, st, Ubwd, DG, DHy, G, C, cnt, abortp, epoch, S, B, stagger, stamps);
+        else
+            hipLaunchKernelGGL((k_bwd_persistent<16, 16, true>), grid, block, 0, st, Ubwd, DG, DHy, G, C, cnt, abortp, epoch, S, B, stagger, stamps);
+        return;
+    }
     switch (N / 32) {
 #define X(k)                                                                                              \
     case k:                                                                                               \
-        hipLaunchKernelGGL((k_bwd_persistent<k>), grid, block, 0, st, Ubwd, DG, DHy, G, C, cnt, abortp, epoch, S, B, stagger); \
+        if (cols == 8)                                                                                    \
+            hipLaunchKernelGGL((k_bwd_persistent<k, 8, false>), grid, block, 0, st, Ubwd, DG, DHy, G, C, cnt, abortp, epoch, S, B, stagger, nullptr); \
+        else                                                                                              \
+            hipLaunchKernelGGL((k_bwd_persistent<k, 16, false>), grid, block, 0, st, Ubwd, DG, DHy, G, C, cnt, abortp, epoch, S, B, stagger, nullptr); \
         break;
         BWD_CASES(X)
 #undef X

@@ -15,13 +15,14 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblstm_hip.so")
+LIB_PATH = os.environ.get("LSTM_HIP_LIB", os.path.join(HERE, "liblstm_hip.so"))  # env override: A/B builds only
 
 FAST_MATH = 1
 NO_GRAPH = 2
 STEP_KERNELS = 4
 GRANULE_HANDOFF = 8
 DEBUG_STAMPS = 16
+NO_OVERLAP = 32
 UNIQUE_ID_BYTES = 128
 VOCAB = 256
 
@@ -242,7 +243,7 @@ class Lstm:
         return out, h0, c0
 
     def debug_stamps(self):
-        out = np.zeros((2, self.S, 8), np.uint64)
+        out = np.zeros((4, self.S, 8), np.uint64)  # [fwd wg0, fwd wg1, bwd wg0, bwd wg1]
         _chk(self.lib.lstm_hip_debug_stamps(self._h, _ptr(out, C.c_uint64), C.c_size_t(out.size)))
         return out
 
