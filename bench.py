@@ -53,6 +53,17 @@ def kernel_flops(N, S, B, M=256):
     }
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, gfx950 x2 read correction applied).  PMC
+    collection cannot run inside this process, so the figure is the recorded one; null if absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        return d["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(N, S, B, text, lr, budget_s=20.0):
     """The oracle's trainer (a port of the reference loop) on this host, 1 thread, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -164,7 +175,7 @@ def main():
             avg_s = ms / calls * 1e-3
             ach = fl[dom] / avg_s / 1e12
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
                         "avg_launch_us": round(avg_s * 1e6, 2), "flop_per_launch": fl[dom],
                         "window_frac": round((24.0 * N * N + 6.0 * 256 * N) * (value / world) / 1e12
                                              / PEAK_FP32_MFMA_TFLOPS, 4)}
