@@ -51,9 +51,12 @@ void fwd_persistent_granules(const float4 *Ufwd, const float *W, const float *bi
 // follower support: a 1-wave kernel that returns once step `t` of launch `epoch` has been published by all
 // `n_prod` producers of every column group (or the abort word is set)
 void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, unsigned *abortp, hipStream_t st);
-void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, unsigned *cnt,
-                    unsigned *abortp, unsigned epoch, int N, int S, int B, int cols, hipStream_t st,
-                    unsigned long long *stamps = nullptr);
+// gpart != null: fused weight-gradient accumulation (dW, dU, db partial blocks per column group, each
+// bwd_partial_floats(N) floats, to be folded in group order); H and xi are then read as well.
+void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,
+                    const int32_t *xi, float *gpart, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
+                    int cols, hipStream_t st, unsigned long long *stamps = nullptr);
+size_t bwd_partial_floats(int N);
 int bwd_group_cols(int N, int B, int n_cus); // 8 or 16 batch columns per backward workgroup
 
 // ---- time-batched dense products (fp32 MFMA 32x32x2, LDS tiled) ------------------------------
@@ -66,7 +69,8 @@ int gemm_pick_splits(int M, int Nn, int K);
 // one K-slice of a split-K product into slab z / the ordered fold of all slabs (time-chunked overlap)
 void gemm_slice(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *slabs,
                 int kchunk, int z, hipStream_t st);
-void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st);
+// slab_stride: floats between consecutive slabs (0 = M*Nn, i.e. densely packed)
+void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st, size_t slab_stride = 0);
 
 // ---- output layer elementwise: probs = exp(y+by)/sum ; loss ; dy = probs - onehot  (R/lstm.cc:195-207,225)
 // Y is [T cols][256] (column-major 256 x T) and is overwritten by dY; probs written to P.

@@ -401,11 +401,11 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int Nn, int K, const float 
 }
 
 __global__ __launch_bounds__(256) void k_gemm_reduce(const float *__restrict__ slabs, int splits, int M, int Nn,
-                                                     float *__restrict__ C, int ldc) {
+                                                     float *__restrict__ C, int ldc, size_t slab_stride) {
     const size_t total = (size_t)M * Nn;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         float s = slabs[e];
-        for (int z = 1; z < splits; z++) s += slabs[(size_t)z * total + e];
+        for (int z = 1; z < splits; z++) s += slabs[(size_t)z * slab_stride + e];
         const size_t m = e % M, n = e / M;
         C[n * ldc + m] = s;
     }
@@ -445,11 +445,13 @@ static void gemm_launch(bool TA, bool TB, int M, int Nn, int K, const float *A, 
 #undef GEMM_NI
 #undef GEMM_LAUNCH
 }
-static void gemm_reduce_launch(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st) {
+static void gemm_reduce_launch(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st,
+                               size_t slab_stride = 0) {
     size_t total = (size_t)M * Nn;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_gemm_reduce, dim3(blocks), dim3(256), 0, st, slabs, splits, M, Nn, C, ldc);
+    hipLaunchKernelGGL(k_gemm_reduce, dim3(blocks), dim3(256), 0, st, slabs, splits, M, Nn, C, ldc,
+                       slab_stride ? slab_stride : total);
 }
 
 void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
@@ -471,8 +473,8 @@ void gemm_slice(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda,
                 int kchunk, int z, hipStream_t st) {
     gemm_launch(TA, TB, M, Nn, K, A, lda, B, ldb, slabs, M, kchunk, (size_t)M * Nn, z, 1, st);
 }
-void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st) {
-    gemm_reduce_launch(slabs, splits, M, Nn, C, ldc, st);
+void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st, size_t slab_stride) {
+    gemm_reduce_launch(slabs, splits, M, Nn, C, ldc, st, slab_stride);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -91,6 +91,7 @@ struct lstm_hip_ctx {
                                // LSTM_HIP_OVERLAP_MASK is set
     int chunk_steps = 0;       // timesteps per follower chunk
     float *slabs_dU = nullptr; // split-K slabs of dU (one per time chunk in overlap mode)
+    float *gpart = nullptr;    // per-column-group partial [dW|dU|db] blocks of the fused backward recurrence
     bool dhy_done = false;
     int bwd_cols = 16;         // batch columns per backward-recurrence workgroup (8 or 16)
 
@@ -306,7 +307,8 @@ int do_backward(lstm_hip_ctx *h) {
         HIP_TRY(hipEventRecord(h->ev_fork, h->st));
         HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
         if (h->st_b) HIP_TRY(hipStreamWaitEvent(h->st_b, h->ev_fork, 0));
-        bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, cb, h->abortp, h->bwd_epoch, N, S, B, h->bwd_cols, sb);
+        bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, nullptr, cb, h->abortp, h->bwd_epoch, N, S, B,
+                       h->bwd_cols, sb);
         HIP_TRY(hipEventRecord(h->ev_main, sb));
         // Followers must not be dispatched before every workgroup of the recurrence has been placed
         // (otherwise the dispatcher packs recurrence workgroups unevenly around them and the whole
@@ -331,9 +333,12 @@ int do_backward(lstm_hip_ctx *h) {
         HIP_TRY(hipStreamWaitEvent(h->st, h->ev_join, 0));
         return 0;
     }
+    bool fused = false;
     if (h->persistent) {
-        RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, cb, h->abortp, h->bwd_epoch, N, S, B, h->bwd_cols,
-                                          h->st, h->stamps ? h->stamps + (size_t)2 * S * 8 : nullptr));
+        fused = h->gpart != nullptr && !h->stamps && h->bwd_cols == 8; // 16-column groups leave too few updater waves
+        RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr, cb,
+                                          h->abortp, h->bwd_epoch, N, S, B, h->bwd_cols, h->st,
+                                          h->stamps ? h->stamps + (size_t)2 * S * 8 : nullptr));
     } else {
         HIP_TRY(hipMemsetAsync(h->dcnext, 0, sizeof(float) * N * B, h->st)); // R/lstm.cc:216-217
         for (int t = S - 1; t >= 1; t--) {
@@ -349,7 +354,14 @@ int do_backward(lstm_hip_ctx *h) {
     RUN(K_GEMM_DU, gemm(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->dP + h->pl.U, G4, h->splits_dU,
                         h->slabs_dU, h->st));
     // dW, db                           R/lstm.cc:251-252
-    RUN(K_DW_DB, dW_db(h->DG + (size_t)G4 * B, h->xi + B, T, G4, h->dP + h->pl.W, h->dP + h->pl.b, h->dw_scratch, h->st));
+    if (fused) { // accumulated per column group inside the recurrence: fold the groups in order
+        const int NGb = (B + h->bwd_cols - 1) / h->bwd_cols;
+        const size_t psz = bwd_partial_floats(N);
+        RUN(K_DW_DB, (gemm_fold(h->gpart, NGb, G4 * 256, 1, h->dP + h->pl.W, G4 * 256, h->st, psz),
+                      gemm_fold(h->gpart + (size_t)G4 * 256 + (size_t)G4 * N, NGb, G4, 1, h->dP + h->pl.b, G4, h->st, psz)));
+    } else {
+        RUN(K_DW_DB, dW_db(h->DG + (size_t)G4 * B, h->xi + B, T, G4, h->dP + h->pl.W, h->dP + h->pl.b, h->dw_scratch, h->st));
+    }
     return 0;
 }
 
@@ -452,6 +464,8 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
     ALLOC(h->abortp, 4);
     h->persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) && persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount);
     h->bwd_cols = bwd_group_cols(cfg->N, cfg->B, prop.multiProcessorCount);
+    if (h->persistent && !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512) // larger N: the dU tiles no longer fit the VGPRs
+        ALLOC(h->gpart, (size_t)((B + h->bwd_cols - 1) / h->bwd_cols) * bwd_partial_floats(cfg->N));
     // followers need whole MFMA k-tiles and whole softmax waves per time chunk
     h->overlap = h->persistent && !(cfg->flags & (LSTM_HIP_NO_OVERLAP | LSTM_HIP_GRANULE_HANDOFF)) && cfg->B % 16 == 0;
     if (const char *e = getenv("LSTM_HIP_OVERLAP_MASK")) h->overlap_mask = atoi(e);
@@ -481,7 +495,7 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     if (h->st2) (void)hipStreamSynchronize(h->st2);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
-                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->Hg, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
+                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->Hg, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -382,26 +382,40 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_g(const float4 *__restri
 #define BSTAMP_AT(k)                                                                     \
     if (STAMP && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
         stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 8 + (k)] = __builtin_amdgcn_s_memtime();
-template <int NR4W, int COLS, bool STAMP = false>
-__global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict__ Ubwd, float *DG,
-                                                        const float *__restrict__ DHy, const float *__restrict__ G,
-                                                        const float *__restrict__ C, unsigned *cnt, unsigned *abortp,
-                                                        unsigned epoch, int S, int B, int stagger,
-                                                        unsigned long long *stamps = nullptr) {
+// FUSE: the input-side weight-gradient sums (R/lstm.cc:251-252) are accumulated by the same workgroups:
+//   dW[rows, x] += dg_t[rows, col] for the column's input byte x   a [257][64] LDS table kept by one wave that
+//                                                          has no part in the elementwise / publish phase
+//   db[rows]    += dg_t[rows, col]                         registers of the elementwise threads
+// The dW update for step t+1 runs during step t (dg is double-buffered in LDS), after the step's second
+// workgroup barrier; the elementwise waves synchronise among themselves through an LDS counter from
+// there on, so the updater never holds up the store / drain / signal / poll path.
+// Each column group g leaves one partial block [dW | (dU, unused) | db] (the layout of the flat gradient
+// block's prefix) in gpart[g]; gemm_fold adds the groups in order afterwards.
+// (Accumulating dU the same way -- 4 x N/16 MFMA accumulator tiles per workgroup -- was built and
+// measured: it needs ~100 more VGPRs, spills, and cost more than the separate GEMM it replaced.)
+template <int NR4W, int COLS, bool FUSE, bool STAMP = false>
+__global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restrict__ Ubwd, float *DG,
+                                                           const float *__restrict__ DHy, const float *__restrict__ G,
+                                                           const float *__restrict__ C, const float *__restrict__ H,
+                                                           const int32_t *__restrict__ xi, float *__restrict__ gpart,
+                                                           unsigned *cnt, unsigned *abortp, unsigned epoch, int S, int B,
+                                                           int stagger, unsigned long long *stamps = nullptr) {
     constexpr int N = 32 * NR4W, G4 = 4 * N, nr4 = N / 4;
+    constexpr int ETH = 16 * COLS;        // threads with an elementwise / store role
+    constexpr int EW = ETH / 64;          // ... i.e. waves 0..EW-1
+    extern __shared__ __attribute__((aligned(16))) float dWt[]; // FUSE: [257][64] per-input-byte sums of this WG's rows
     __shared__ float red[8 * 4 * 64];
-    __shared__ __attribute__((aligned(16))) float stage[16 * 4 * 16];
+    __shared__ __attribute__((aligned(16))) float stage[2][16 * 4 * 16]; // dg of this WG, double-buffered by step parity
     __shared__ int s_abort;
+    __shared__ unsigned s_pair; // arrivals of the elementwise waves at their private sync points
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int kb = blockIdx.x, g = blockIdx.y, NBK = gridDim.x, NG = gridDim.y;
     const int q = l >> 4;
-    // COLS = 16: the MFMA tile is full.  COLS = 8: lanes 8..15 of the B operand repeat columns 0..7 and
-    // half of the tile is discarded -- the matrix pipe is not what bounds a step; the dg_{t+1} bytes each
-    // CU must pull over the fabric are (K x COLS floats), and 8-column groups halve them per CU while
-    // doubling the number of CUs at work.
-    constexpr int ETH = 16 * COLS; // threads with an elementwise / store role
+    // COLS = 16: the MFMA tile is full.  COLS = 8: lanes 8..15 of the B operand are never used (their tile
+    // columns are discarded) -- the matrix pipe is not what bounds a step, and 8-column groups put
+    // twice as many CUs to work on half the dg_{t+1} bytes each.
     const int mcol = COLS * g + (l & (COLS - 1)), mcolc = mcol < B ? mcol : B - 1; // MFMA B-operand column
-    // epilogue role (threads 0..ETH-1): unit jj, column cc
+    // elementwise role (threads 0..ETH-1): unit jj, column cc
     const int jj = tid & 15, cc = (tid >> 4) & (COLS - 1);
     const int ecol = COLS * g + cc, ecolc = ecol < B ? ecol : B - 1;
     const int j = 16 * kb + jj;
@@ -413,14 +427,52 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
     for (int i = 0; i < NR4W; i++) a[i] = Ubwd[((size_t)kb * nr4 + w * NR4W + i) * 64 + l];
     const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG, (size_t)S * G4 * B * sizeof(float));
     float dcn = 0.0f; // dcnext, R/lstm.cc:217
-    if (tid == 0) s_abort = 0;
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FUSE)
+        for (int i = tid; i < 257 * 64; i += 512) dWt[i] = 0.0f;
+    if (tid == 0) {
+        s_abort = 0;
+        s_pair = 0;
+    }
+    unsigned pair_target = 0;
     __syncthreads();
     if (!STAMP)
         for (int i = 0; i < g * stagger; i++) __builtin_amdgcn_s_sleep(32); // see k_fwd_persistent
 
+    // sync point of the EW elementwise waves only (LDS counter; LDS operations of a wave complete in order)
+    auto pair_sync = [&]() {
+        pair_target += EW;
+        if (EW > 1) {
+            if (l == 0) __hip_atomic_fetch_add(&s_pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(&s_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < pair_target) {
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+    // dW[:, x] += dg[:, col] (R/lstm.cc:251) for the step whose dg sits in stage[par]: wave EW, one thread per
+    // row, walking the columns in order (deterministic); tu is that step
+    auto update = [&](int par, int tu) {
+        if (w == EW) {
+            int xs[COLS];
+#pragma unroll
+            for (int c = 0; c < COLS; c++) {
+                const int col = COLS * g + c;
+                const int x = col < B ? xi[(size_t)tu * B + col] : -2;
+                xs[c] = x == -1 ? 256 : x; // -1: empty input column -> bucket 256; -2: padding column, skipped
+            }
+            const float *sg_ = stage[par];
+            const int gt = l >> 4, rj = l & 15;
+#pragma unroll
+            for (int c = 0; c < COLS; c++)
+                if (xs[c] >= 0) dWt[xs[c] * 64 + l] += sg_[(c * 4 + gt) * 16 + rj];
+        }
+    };
+
     for (int t = S - 1; t >= 1; t--) {
         BSTAMP_AT(0)
-        // operands of the elementwise part do not depend on the chain: fetch them first
+        const int cur = t & 1;
+        const bool has_next = t < S - 1;
+        // operands that do not depend on the chain: fetch them first
         float ig = 0.f, og = 0.f, fg = 0.f, ug = 0.f, cv = 0.f, cp = 0.f, dhy = 0.f;
         if (tid < ETH) {
             const float *gc = G + ((size_t)t * B + ecolc) * G4 + j;
@@ -432,7 +484,6 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
             cp = C[((size_t)(t - 1) * B + ecolc) * N + j];
             dhy = DHy[((size_t)t * B + ecolc) * N + j];
         }
-        const bool has_next = t < S - 1;
         if (has_next && w == 0) {
             const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * 8 * CNT_STRIDE;
             if (!wait_arrivals(cpn, NBK, epoch, abortp, l) && l == 0) s_abort = 1;
@@ -447,10 +498,8 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
             // Software pipeline with PF fragment loads in flight ahead of the MFMAs.  Left to itself the
             // scheduler keeps only two in flight (a fabric round trip per pair of loads: measured +220
             // cycles per load), and all NR4W at once measured slower still; sched_barriers pin the order.
-            // COLS = 8: tile columns 8..15 are discarded, so their B operand may be anything -- those lanes
-            // issue no load at all.
             constexpr int PF = BWD_PF < NR4W ? BWD_PF : NR4W;
-            const bool ld_lane = COLS == 16 || (l & 15) < COLS;
+            const bool ld_lane = COLS == 16 || (l & 15) < COLS; // discarded tile columns issue no load
             float4 b[NR4W];
 #pragma unroll
             for (int i = 0; i < PF; i++)
@@ -479,14 +528,14 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
             for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
             __syncthreads();
             BSTAMP_AT(2)
-            if (tid < ETH) {
+        }
+        if (w < EW) {
+            if (has_next) {
                 // D[row = 4*(lane>>4) + reg][col = lane&15]  ->  unit jj lives in lane (jj>>2)*16 + cc, reg jj&3
                 const int src = (jj >> 2) * 16 + cc, reg = jj & 3;
 #pragma unroll
                 for (int ww = 0; ww < 8; ww++) dhn += red[(ww * 4 + reg) * 64 + src];
             }
-        }
-        if (tid < ETH) {
             const float dh = dhy + dhn;                         // R/lstm.cc:228
             float dcv = dh * og + dcn;                          // :233
             dcv = dcv * (1.0f - cv * cv);                       // :235
@@ -495,28 +544,57 @@ __global__ __launch_bounds__(512) void k_bwd_persistent(const float4 *__restrict
             const float d_f = (dcv * cp) * (fg * (1.0f - fg));  // :240,244
             const float d_u = (dcv * ig) * (1.0f - ug * ug);    // :241,247
             dcn = dcv * fg;                                     // :256
-            float *sp = stage + (cc * 4) * 16 + jj;
+            if (FUSE && ecol < B) {                             // db += dg, R/lstm.cc:252
+                dbacc[0] += d_i;
+                dbacc[1] += d_o;
+                dbacc[2] += d_f;
+                dbacc[3] += d_u;
+            }
+            float *sp = stage[cur] + (cc * 4) * 16 + jj;
             sp[0] = d_i;
             sp[16] = d_o;
             sp[32] = d_f;
             sp[48] = d_u;
-        }
-        __syncthreads();
-        BSTAMP_AT(3)
-        if (tid < ETH) {
+            pair_sync();
+            BSTAMP_AT(3)
             const int scol = COLS * g + sc;
             if (scol < B) {
-                const float4 v = *reinterpret_cast<const float4 *>(stage + (sc * 4 + sg) * 16 + 4 * sq);
+                const float4 v = *reinterpret_cast<const float4 *>(stage[cur] + (sc * 4 + sg) * 16 + 4 * sq);
                 st_sc1(v, rDG, (int)((((size_t)t * B + scol) * G4 + sg * N + 16 * kb + 4 * sq) * sizeof(float)));
             }
+            if (t > 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the signal
+                pair_sync();
+                BSTAMP_AT(4)
+                if (tid == 0)
+                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * 8 + (kb & 7)) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (FUSE && has_next) {
+            update(cur ^ 1, t + 1); // dg_{t+1}, published a step ago; this wave is off the critical path
         }
-        if (t > 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the signal
-            __syncthreads();
-            BSTAMP_AT(4)
-            if (tid == 0)
-                __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * 8 + (kb & 7)) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (FUSE) {
+        __syncthreads();
+        update(1, 1); // dg_1
+        __syncthreads();
+        float *base = gpart + (size_t)g * ((size_t)G4 * 256 + (size_t)G4 * N + G4);
+        // dW partial: table row r = gate*16 + unit  ->  gradient row gate*N + 16*kb + unit
+        for (int i = tid; i < 256 * 64; i += 512) {
+            const int x = i >> 6, r = i & 63;
+            base[(size_t)x * G4 + (r >> 4) * N + 16 * kb + (r & 15)] = dWt[i];
+        }
+        // db partial: fold the columns in order
+        if (tid < ETH) {
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) red[(cc * 4 + gt) * 16 + jj] = dbacc[gt];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int gt = tid >> 4, rj = tid & 15;
+            float sum = 0.0f;
+            for (int c = 0; c < COLS; c++) sum += red[(c * 4 + gt) * 16 + rj];
+            base[(size_t)G4 * 256 + (size_t)G4 * N + gt * N + 16 * kb + rj] = sum;
         }
     }
 }
@@ -563,7 +641,7 @@ bool persistent_supported(int N, int B, int n_cus) {
         default: return false;
     }
     switch (N / 32) {
-#define X(k) case k: bb = blocks_per_cu(k_bwd_persistent<k, 16, false>, 512); break;
+#define X(k) case k: bb = blocks_per_cu(k_bwd_persistent<k, 16, false, false>, 512); break;
         BWD_CASES(X)
 #undef X
         default: return false;
@@ -616,30 +694,44 @@ int bwd_group_cols(int N, int B, int n_cus) {
     if (force == 8 || force == 16) return force;
     return (N / 16) * ((B + 7) / 8) <= n_cus && B > 8 ? 8 : 16;
 }
+// floats in one column group's partial gradient block [dW | dU | db]
+size_t bwd_partial_floats(int N) { return (size_t)4 * N * 256 + (size_t)4 * N * N + (size_t)4 * N; }
 
-void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, unsigned *cnt,
-                    unsigned *abortp, unsigned epoch, int N, int S, int B, int cols, hipStream_t st,
-                    unsigned long long *stamps) {
+void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,
+                    const int32_t *xi, float *gpart, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
+                    int cols, hipStream_t st, unsigned long long *stamps) {
     const dim3 grid(N / 16, (B + cols - 1) / cols), block(512);
     static const int stagger = getenv("LSTM_HIP_BWD_STAGGER") ? atoi(getenv("LSTM_HIP_BWD_STAGGER")) : 0;
+    const bool fuse = gpart != nullptr;
+    const size_t lds = fuse ? 257 * 64 * sizeof(float) : 0;
+#define BWD_LAUNCH(k, c, f, s)                                                                                        \
+    do {                                                                                                              \
+        if (f) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persistent<k, c, f, s>),              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 257 * 64 * sizeof(float));      \
+        hipLaunchKernelGGL((k_bwd_persistent<k, c, f, s>), grid, block, lds, st, Ubwd, DG, DHy, G, C, H, xi, gpart, cnt, \
+                           abortp, epoch, S, B, stagger, stamps);                                                     \
+    } while (0)
     if (stamps != nullptr && N == 512) {
-        if (cols == 8)
-            hipLaunchKernelGGL((k_bwd_persistent<16, 8, true>), grid, block, 0, st, Ubwd, DG, DHy, G, C, cnt, abortp, epoch, S, B, stagger, stamps);
-        else
-            hipLaunchKernelGGL((k_bwd_persistent<16, 16, true>), grid, block, 0, st, Ubwd, DG, DHy, G, C, cnt, abortp, epoch, S, B, stagger, stamps);
+        if (cols == 8) BWD_LAUNCH(16, 8, false, true);
+        else BWD_LAUNCH(16, 16, false, true);
         return;
     }
+    stamps = nullptr;
     switch (N / 32) {
-#define X(k)                                                                                              \
-    case k:                                                                                               \
-        if (cols == 8)                                                                                    \
-            hipLaunchKernelGGL((k_bwd_persistent<k, 8, false>), grid, block, 0, st, Ubwd, DG, DHy, G, C, cnt, abortp, epoch, S, B, stagger, nullptr); \
-        else                                                                                              \
-            hipLaunchKernelGGL((k_bwd_persistent<k, 16, false>), grid, block, 0, st, Ubwd, DG, DHy, G, C, cnt, abortp, epoch, S, B, stagger, nullptr); \
+#define X(k)                                    \
+    case k:                                     \
+        if (cols == 8) {                        \
+            if (fuse) BWD_LAUNCH(k, 8, true, false);  \
+            else BWD_LAUNCH(k, 8, false, false);      \
+        } else {                                \
+            if (fuse) BWD_LAUNCH(k, 16, true, false); \
+            else BWD_LAUNCH(k, 16, false, false);     \
+        }                                       \
         break;
         BWD_CASES(X)
 #undef X
     }
+#undef BWD_LAUNCH
 }
 
 } // namespace lstmk

@@ -23,6 +23,7 @@ STEP_KERNELS = 4
 GRANULE_HANDOFF = 8
 DEBUG_STAMPS = 16
 NO_OVERLAP = 32
+NO_FUSED_GRADS = 64
 UNIQUE_ID_BYTES = 128
 VOCAB = 256
 

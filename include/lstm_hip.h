@@ -50,6 +50,8 @@ extern "C" {
 #define LSTM_HIP_GRANULE_HANDOFF 8u /* forward hand-off by 8-byte {value, tag} granules instead of the default sc1
                                       payload + sharded counters (measured 1.6-1.9x slower; kept for A/B runs) */
 
+#define LSTM_HIP_NO_FUSED_GRADS 64u  /* compute dU/dW/db after the backward recurrence (GEMM + sorted segment sums)
+                                      instead of accumulating them inside it */
 #define LSTM_HIP_NO_OVERLAP 32u      /* run the time-batched products after the recurrences instead of beside them */
 #define LSTM_HIP_DEBUG_STAMPS 16u    /* diagnostic build of the forward recurrence (N = 512) that records
                                       s_memtime at five points of every step; see lstm_hip_debug_stamps */
