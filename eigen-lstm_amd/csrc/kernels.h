@@ -51,11 +51,12 @@ void fwd_persistent_granules(const float4 *Ufwd, const float *W, const float *bi
 // follower support: a 1-wave kernel that returns once step `t` of launch `epoch` has been published by all
 // `n_prod` producers of every column group (or the abort word is set)
 void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, unsigned *abortp, hipStream_t st);
-// gpart != null: fused weight-gradient accumulation (dW, dU, db partial blocks per column group, each
-// bwd_partial_floats(N) floats, to be folded in group order); H and xi are then read as well.
+// gpart != null (8-column groups only): fused mode.  The recurrence then also produces DHy on the fly from
+// Why and dY (DHy is not read), and leaves per-column-group partial blocks [dW | - | db | dWhy]
+// (bwd_partial_floats(N) floats each) to be folded in group order; H and xi are read as well.
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,
-                    const int32_t *xi, float *gpart, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
-                    int cols, hipStream_t st, unsigned long long *stamps = nullptr);
+                    const int32_t *xi, float *gpart, const float *Why, const float *dY, unsigned *cnt, unsigned *abortp,
+                    unsigned epoch, int N, int S, int B, int cols, hipStream_t st, unsigned long long *stamps = nullptr);
 size_t bwd_partial_floats(int N);
 int bwd_group_cols(int N, int B, int n_cus); // 8 or 16 batch columns per backward workgroup
 

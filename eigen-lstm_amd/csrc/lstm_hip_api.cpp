@@ -290,7 +290,9 @@ int do_backward(lstm_hip_ctx *h) {
                                h->dP + h->pl.by, h->st));
     h->dby_done = false;
     // DHy = Why^T * dY                 R/lstm.cc:228, all steps (already done by the forward's followers in overlap mode)
-    if (!h->dhy_done)
+    // fused mode: the backward recurrence produces DHy itself and accumulates dW, db, dWhy
+    const bool fused = h->persistent && h->gpart != nullptr && !h->stamps && h->bwd_cols == 8 && !overlap_now(h, 2);
+    if (!h->dhy_done && !fused)
         RUN(K_GEMM_DHY, gemm(true, false, N, T, 256, h->P + h->pl.Why, 256, dY, 256, h->DHy + (size_t)N * B, N, 1, nullptr,
                              h->st));
     h->dhy_done = false;
@@ -307,8 +309,8 @@ int do_backward(lstm_hip_ctx *h) {
         HIP_TRY(hipEventRecord(h->ev_fork, h->st));
         HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
         if (h->st_b) HIP_TRY(hipStreamWaitEvent(h->st_b, h->ev_fork, 0));
-        bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, nullptr, cb, h->abortp, h->bwd_epoch, N, S, B,
-                       h->bwd_cols, sb);
+        bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, nullptr, nullptr, nullptr, cb, h->abortp,
+                       h->bwd_epoch, N, S, B, h->bwd_cols, sb);
         HIP_TRY(hipEventRecord(h->ev_main, sb));
         // Followers must not be dispatched before every workgroup of the recurrence has been placed
         // (otherwise the dispatcher packs recurrence workgroups unevenly around them and the whole
@@ -333,11 +335,9 @@ int do_backward(lstm_hip_ctx *h) {
         HIP_TRY(hipStreamWaitEvent(h->st, h->ev_join, 0));
         return 0;
     }
-    bool fused = false;
     if (h->persistent) {
-        fused = h->gpart != nullptr && !h->stamps && h->bwd_cols == 8; // 16-column groups leave too few updater waves
-        RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr, cb,
-                                          h->abortp, h->bwd_epoch, N, S, B, h->bwd_cols, h->st,
+        RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr,
+                                          h->P + h->pl.Why, dY, cb, h->abortp, h->bwd_epoch, N, S, B, h->bwd_cols, h->st,
                                           h->stamps ? h->stamps + (size_t)2 * S * 8 : nullptr));
     } else {
         HIP_TRY(hipMemsetAsync(h->dcnext, 0, sizeof(float) * N * B, h->st)); // R/lstm.cc:216-217
@@ -348,8 +348,9 @@ int do_backward(lstm_hip_ctx *h) {
         }
     }
     // dWhy = dY * H[1..]^T             R/lstm.cc:226
-    RUN(K_GEMM_DWHY, gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256,
-                          h->splits_dWhy, h->slabs, h->st));
+    if (!fused)
+        RUN(K_GEMM_DWHY, gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256,
+                              h->splits_dWhy, h->slabs, h->st));
     // dU = DG * H[0..S-2]^T            R/lstm.cc:250
     RUN(K_GEMM_DU, gemm(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->dP + h->pl.U, G4, h->splits_dU,
                         h->slabs_dU, h->st));
@@ -357,8 +358,10 @@ int do_backward(lstm_hip_ctx *h) {
     if (fused) { // accumulated per column group inside the recurrence: fold the groups in order
         const int NGb = (B + h->bwd_cols - 1) / h->bwd_cols;
         const size_t psz = bwd_partial_floats(N);
+        // b and Why are adjacent both in the flat block and in the partial blocks: one fold covers both
         RUN(K_DW_DB, (gemm_fold(h->gpart, NGb, G4 * 256, 1, h->dP + h->pl.W, G4 * 256, h->st, psz),
-                      gemm_fold(h->gpart + (size_t)G4 * 256 + (size_t)G4 * N, NGb, G4, 1, h->dP + h->pl.b, G4, h->st, psz)));
+                      gemm_fold(h->gpart + (size_t)G4 * 256 + (size_t)G4 * N, NGb, G4 + 256 * N, 1, h->dP + h->pl.b,
+                                G4 + 256 * N, h->st, psz)));
     } else {
         RUN(K_DW_DB, dW_db(h->DG + (size_t)G4 * B, h->xi + B, T, G4, h->dP + h->pl.W, h->dP + h->pl.b, h->dw_scratch, h->st));
     }

@@ -389,8 +389,10 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_g(const float4 *__restri
 // The dW update for step t+1 runs during step t (dg is double-buffered in LDS), after the step's second
 // workgroup barrier; the elementwise waves synchronise among themselves through an LDS counter from
 // there on, so the updater never holds up the store / drain / signal / poll path.
-// Each column group g leaves one partial block [dW | (dU, unused) | db] (the layout of the flat gradient
-// block's prefix) in gpart[g]; gemm_fold adds the groups in order afterwards.
+//   DHy_t = Why^T*dy_t (R/lstm.cc:228) for this workgroup's 16 units, one step ahead of its use, and
+//   dWhy[:, units] += dy_t * h_t[units]^T (R/lstm.cc:226)    four "follower" waves (4..7), 24 MFMAs a step
+// Each column group g leaves one partial block [dW | (dU, unused) | db | dWhy] (the layout of the flat
+// gradient block) in gpart[g]; gemm_fold adds the groups in order afterwards.
 // (Accumulating dU the same way -- 4 x N/16 MFMA accumulator tiles per workgroup -- was built and
 // measured: it needs ~100 more VGPRs, spills, and cost more than the separate GEMM it replaced.)
 template <int NR4W, int COLS, bool FUSE, bool STAMP = false>
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                                                            const float *__restrict__ DHy, const float *__restrict__ G,
                                                            const float *__restrict__ C, const float *__restrict__ H,
                                                            const int32_t *__restrict__ xi, float *__restrict__ gpart,
+                                                           const float *__restrict__ Why, const float *__restrict__ dY,
                                                            unsigned *cnt, unsigned *abortp, unsigned epoch, int S, int B,
                                                            int stagger, unsigned long long *stamps = nullptr) {
     constexpr int N = 32 * NR4W, G4 = 4 * N, nr4 = N / 4;
@@ -408,6 +411,11 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     __shared__ __attribute__((aligned(16))) float stage[2][16 * 4 * 16]; // dg of this WG, double-buffered by step parity
     __shared__ int s_abort;
     __shared__ unsigned s_pair; // arrivals of the elementwise waves at their private sync points
+    // FUSE: output-layer followers (waves 4..7): DHy_t = Why^T * dy_t for this workgroup's units, one step
+    // ahead of its use, and the dWhy columns of those units
+    __shared__ float olred[4 * 4 * 64];
+    __shared__ float dhyb[2][16 * 16];
+    __shared__ unsigned s_ol;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int kb = blockIdx.x, g = blockIdx.y, NBK = gridDim.x, NG = gridDim.y;
     const int q = l >> 4;
@@ -433,8 +441,26 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     if (tid == 0) {
         s_abort = 0;
         s_pair = 0;
+        s_ol = 0;
     }
-    unsigned pair_target = 0;
+    unsigned pair_target = 0, ol_target = 0;
+    // Why^T A-fragments of the follower waves: wave ow = w-4 takes output rows m in [64*ow, 64*ow+64);
+    // fragment i of k-step ks4 is Why[m = 64*ow + 16*ks4 + 4*(l>>4) + i][16*kb + (l&15)]
+    float4 wa[FUSE ? 4 : 1];
+    f32x4 yacc[FUSE ? 4 : 1]; // dWhy tiles: rows m in [16*(4*ow+mt), +16), columns 16*kb..+15
+    if (FUSE) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) yacc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (w >= 4) {
+            const int ow = w - 4;
+#pragma unroll
+            for (int ks4 = 0; ks4 < 4; ks4++) {
+                const int m = 64 * ow + 16 * ks4 + 4 * q;
+                const float *wp = Why + (size_t)(16 * kb + (l & 15)) * 256 + m;
+                wa[ks4] = *reinterpret_cast<const float4 *>(wp);
+            }
+        }
+    }
     __syncthreads();
     if (!STAMP)
         for (int i = 0; i < g * stagger; i++) __builtin_amdgcn_s_sleep(32); // see k_fwd_persistent
@@ -468,6 +494,79 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
         }
     };
 
+    // Output-layer work of step tu by the follower waves (R/lstm.cc:226,228):
+    //   dhyb[tu&1][c][unit] = sum_m Why[m][unit] * dy_tu[m][c]            (K = 256 split over the 4 waves)
+    //   dWhy[m][unit]      += sum_c dy_tu[m][c] * h_tu[unit][c]           (K = COLS)
+    auto ol_sync = [&]() {
+        ol_target += 4;
+        if (l == 0) __hip_atomic_fetch_add(&s_ol, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&s_ol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ol_target) {
+        }
+        asm volatile("" ::: "memory");
+    };
+    // operands are fetched a whole chain phase ahead of their use (the followers must not arrive late at
+    // the workgroup barrier that opens the next step)
+    float4 ol_dy[FUSE ? 4 : 1];
+    float ol_av[FUSE ? COLS / 4 : 1][FUSE ? 4 : 1], ol_hv[FUSE ? COLS / 4 : 1];
+    auto output_layer_fetch = [&](int tu) {
+        const int ow = w - 4;
+        const int c = l & 15, col = COLS * g + c;
+        const bool cvalid = c < COLS && col < B;
+        const float *dyc = dY + ((size_t)(tu - 1) * B + (cvalid ? col : 0)) * 256; // dY holds steps 1.. at column (t-1)*B+b
+#pragma unroll
+        for (int ks4 = 0; ks4 < 4; ks4++) {
+            ol_dy[ks4] = float4{0.f, 0.f, 0.f, 0.f};
+            if (cvalid) ol_dy[ks4] = *reinterpret_cast<const float4 *>(dyc + 64 * ow + 16 * ks4 + 4 * q);
+        }
+#pragma unroll
+        for (int ks = 0; ks < COLS / 4; ks++) {
+            const int kc = COLS * g + 4 * ks + q;
+            const bool kvalid = kc < B;
+            ol_hv[ks] = kvalid ? H[((size_t)tu * B + kc) * N + 16 * kb + (l & 15)] : 0.0f;
+            const float *dyk = dY + ((size_t)(tu - 1) * B + (kvalid ? kc : 0)) * 256 + 64 * ow + (l & 15);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) ol_av[ks][mt] = kvalid ? dyk[16 * mt] : 0.0f;
+        }
+    };
+    auto output_layer = [&](int tu) {
+        const int ow = w - 4;
+        const int c = l & 15;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks4 = 0; ks4 < 4; ks4++) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks4].x, ol_dy[ks4].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks4].y, ol_dy[ks4].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks4].z, ol_dy[ks4].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks4].w, ol_dy[ks4].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) olred[(ow * 4 + r) * 64 + l] = acc[r];
+        // dWhy: A[i = m in tile][k = column], B[k = column][j = unit]
+#pragma unroll
+        for (int ks = 0; ks < COLS / 4; ks++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+                yacc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ol_av[ks][mt], ol_hv[ks], yacc[mt], 0, 0, 0);
+        ol_sync();
+        // fold the four K-quarters: D[row = unit = 4*(lane>>4)+reg][col = c = lane&15]
+        if (ow == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float v = ((olred[(0 * 4 + r) * 64 + l] + olred[(1 * 4 + r) * 64 + l]) + olred[(2 * 4 + r) * 64 + l]) +
+                                olred[(3 * 4 + r) * 64 + l];
+                dhyb[tu & 1][c * 16 + 4 * q + r] = v;
+            }
+        }
+        ol_sync(); // olred may be rewritten
+    };
+    if (FUSE) {
+        if (w >= 4) {
+            output_layer_fetch(S - 1);
+            output_layer(S - 1);
+        }
+        __syncthreads();
+    }
+
     for (int t = S - 1; t >= 1; t--) {
         BSTAMP_AT(0)
         const int cur = t & 1;
@@ -482,8 +581,9 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
             ug = gc[3 * N];
             cv = C[((size_t)t * B + ecolc) * N + j];
             cp = C[((size_t)(t - 1) * B + ecolc) * N + j];
-            dhy = DHy[((size_t)t * B + ecolc) * N + j];
+            if (!FUSE) dhy = DHy[((size_t)t * B + ecolc) * N + j];
         }
+        if (FUSE && w >= 4 && t >= 2) output_layer_fetch(t - 1);
         if (has_next && w == 0) {
             const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * 8 * CNT_STRIDE;
             if (!wait_arrivals(cpn, NBK, epoch, abortp, l) && l == 0) s_abort = 1;
@@ -530,6 +630,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
             BSTAMP_AT(2)
         }
         if (w < EW) {
+            if (FUSE) dhy = dhyb[cur][cc * 16 + jj]; // written by the followers one step ago (before barrier A)
             if (has_next) {
                 // D[row = 4*(lane>>4) + reg][col = lane&15]  ->  unit jj lives in lane (jj>>2)*16 + cc, reg jj&3
                 const int src = (jj >> 2) * 16 + cc, reg = jj & 3;
@@ -570,19 +671,33 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                     __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * 8 + (kb & 7)) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
             }
-        } else if (FUSE && has_next) {
-            update(cur ^ 1, t + 1); // dg_{t+1}, published a step ago; this wave is off the critical path
+        } else if (FUSE) {
+            if (w == EW && has_next) update(cur ^ 1, t + 1); // dg_{t+1}, published a step ago; off the critical path
+            if (w >= 4 && t >= 2) output_layer(t - 1);       // one step ahead of its use
         }
     }
     if (FUSE) {
         __syncthreads();
         update(1, 1); // dg_1
         __syncthreads();
-        float *base = gpart + (size_t)g * ((size_t)G4 * 256 + (size_t)G4 * N + G4);
+        float *base = gpart + (size_t)g * ((size_t)G4 * 256 + (size_t)G4 * N + G4 + (size_t)256 * N);
         // dW partial: table row r = gate*16 + unit  ->  gradient row gate*N + 16*kb + unit
         for (int i = tid; i < 256 * 64; i += 512) {
             const int x = i >> 6, r = i & 63;
             base[(size_t)x * G4 + (r >> 4) * N + 16 * kb + (r & 15)] = dWt[i];
+        }
+        // dWhy partial: D[row = m in tile = 4*(lane>>4)+reg][col = unit = lane&15]
+        if (w >= 4) {
+            float *Yp = base + (size_t)G4 * 256 + (size_t)G4 * N + G4;
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                float4 v;
+                v.x = yacc[mt][0];
+                v.y = yacc[mt][1];
+                v.z = yacc[mt][2];
+                v.w = yacc[mt][3];
+                *reinterpret_cast<float4 *>(Yp + (size_t)(16 * kb + (l & 15)) * 256 + 64 * (w - 4) + 16 * mt + 4 * q) = v;
+            }
         }
         // db partial: fold the columns in order
         if (tid < ETH) {
@@ -695,11 +810,11 @@ int bwd_group_cols(int N, int B, int n_cus) {
     return (N / 16) * ((B + 7) / 8) <= n_cus && B > 8 ? 8 : 16;
 }
 // floats in one column group's partial gradient block [dW | dU | db]
-size_t bwd_partial_floats(int N) { return (size_t)4 * N * 256 + (size_t)4 * N * N + (size_t)4 * N; }
+size_t bwd_partial_floats(int N) { return (size_t)4 * N * 256 + (size_t)4 * N * N + (size_t)4 * N + (size_t)256 * N; }
 
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,
-                    const int32_t *xi, float *gpart, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
-                    int cols, hipStream_t st, unsigned long long *stamps) {
+                    const int32_t *xi, float *gpart, const float *Why, const float *dY, unsigned *cnt, unsigned *abortp,
+                    unsigned epoch, int N, int S, int B, int cols, hipStream_t st, unsigned long long *stamps) {
     const dim3 grid(N / 16, (B + cols - 1) / cols), block(512);
     static const int stagger = getenv("LSTM_HIP_BWD_STAGGER") ? atoi(getenv("LSTM_HIP_BWD_STAGGER")) : 0;
     const bool fuse = gpart != nullptr;
@@ -708,8 +823,8 @@ void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float
     do {                                                                                                              \
         if (f) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persistent<k, c, f, s>),              \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 257 * 64 * sizeof(float));      \
-        hipLaunchKernelGGL((k_bwd_persistent<k, c, f, s>), grid, block, lds, st, Ubwd, DG, DHy, G, C, H, xi, gpart, cnt, \
-                           abortp, epoch, S, B, stagger, stamps);                                                     \
+        hipLaunchKernelGGL((k_bwd_persistent<k, c, f, s>), grid, block, lds, st, Ubwd, DG, DHy, G, C, H, xi, gpart, Why, dY, \
+                           cnt, abortp, epoch, S, B, stagger, stamps);                                                     \
     } while (0)
     if (stamps != nullptr && N == 512) {
         if (cols == 8) BWD_LAUNCH(16, 8, false, true);

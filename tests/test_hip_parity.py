@@ -25,6 +25,7 @@ CASES = [
     (48, 2, 3, ()),                      # S = 2: a single timestep
     (128, 25, 1, ()),                    # BASELINE configs[0] shape (alice29 N=128 S=25 B=1)
     (256, 50, 32, ()),                   # BASELINE configs[1] shape
+    (1024, 4, 16, ()),                   # widest persistent instantiation (BASELINE configs[4] hidden size, fp32)
 ]
 
 
@@ -91,6 +92,22 @@ def test_window_matches_oracle(N, S, B, empty, oracle32):
     mask = np.abs(dref) > 1e-3 * np.abs(dref).max()
     assert np.abs(got["params"][mask] - Pref[mask]).max() <= 2e-4 * lr + 1e-6
     np.testing.assert_allclose(got["mem"], mref, rtol=1e-3, atol=1e-3 * float(mref.max()))
+
+
+@pytest.mark.parametrize("flag_name", ["GRANULE_HANDOFF", "NO_FUSED_GRADS", "STEP_KERNELS"])
+def test_alternative_engines_agree(flag_name, oracle32):
+    """The A/B switches kept in the library (granule hand-off, unfused dW/db, per-step engine) compute the
+    same window as the default path."""
+    import lstm_hip
+    N, S, B = 128, 9, 24
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=31, empty=((1, 3),))
+    fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
+    dref = oracle32.backward(N, 256, S, B, P, xi, ti, fw)
+    got = _run_hip(lstm_hip, N, S, B, P, xi, ti, h0, c0, flags=getattr(lstm_hip, flag_name))
+    assert gu.max_rel(got["h"][-1], fw["h"][S - 1]) <= ACT_TOL
+    assert abs(got["loss"] - fw["loss_bits"]) <= LOSS_TOL * (S - 1)
+    rep = gu.grads_report(got["grads"], dref, N)
+    assert max(rep.values()) <= GRAD_TOL, rep
 
 
 def test_fast_math_flag_stays_close(oracle32):
@@ -277,3 +294,28 @@ def test_headline_shape_one_window_vs_oracle():
     np.testing.assert_allclose(np.sum(got["probs"][-1], axis=1), 1.0, atol=1e-5)
     np.testing.assert_allclose(g["W"].sum(axis=1), g["b"][:, 0], rtol=1e-3, atol=1e-3 * np.abs(g["b"]).max())
     assert abs(g["by"].sum()) <= 1e-2
+
+
+def test_rccl_path_with_a_single_rank_communicator():
+    """The RCCL leg (dlopen, ncclGetUniqueId, ncclCommInitRank, ncclAllReduce on the library's stream) with a
+    1-rank communicator: the all-reduce must leave the gradients, hence the whole trajectory, unchanged."""
+    import lstm_hip
+    N, S, B, windows = 64, 8, 16, 6
+    text = _synthetic_text(500, seed=9)
+
+    def run(with_comm):
+        L = lstm_hip.Lstm(N, S, B)
+        L.set_params(lstm_hip.init_params(lstm_hip.MT19937Normal(3), N))
+        L.set_text(text)
+        L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
+        if with_comm:
+            L.comm_init(lstm_hip.comm_unique_id(), 1, 0)
+            L.set_global_batch(B)
+        losses = L.train_windows(windows, 0.05)
+        P = L.get_params()
+        L.close()
+        return losses, P
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert np.array_equal(l0, l1) and np.array_equal(p0, p1)
