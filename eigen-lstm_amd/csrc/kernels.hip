@@ -8,6 +8,8 @@
 //   v_mfma_f32_32x32x2_f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D[row=(reg&3)+8*(reg>>2)+4*(l>>5)][col=l&31]
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace lstmk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -284,70 +286,101 @@ void bwd_step(const float4 *Ubwd, const float *DGnext, const float *DHy_t, const
 // row index) so the accumulator holds C^T fragments: lanes then run along m, which is contiguous in
 // column-major C, and the epilogue stores are coalesced.
 // ------------------------------------------------------------------------------------------------
-constexpr int GBM = 128, GBK = 16, GLD = 132; // BN = 64*NI (NI = 1 or 2 n-fragments of 32 per wave)
+constexpr int GBK = 16; // k-tile depth; tile = (64*MW) x (64*NI) with 2*MW waves of 64 x (32*NI)
 
-// ROWS = 128 or 64 tile rows (m or n); a 64-row tile needs one float4 per thread (q = 0 only)
-template <bool TRANS, int ROWS> // TRANS=false: source is [rows contiguous] x K ; TRANS=true: source is K-contiguous
-__device__ __forceinline__ void gemm_load(const float *__restrict__ src, int ld, int r0, int rmax, int k0, int kend,
-                                          int tid, float4 (&reg)[2]) {
+// Tile loaders.  ROWS = tile rows (m or n), NT = threads.  TRANS=false: the source is [rows contiguous] x K
+// (a float4 is 4 consecutive rows of one k); TRANS=true: the source is K-contiguous (a float4 is 4
+// consecutive k of one row).  The LDS image is always [k][row] with row stride ROWS+4.
+template <bool TRANS, int ROWS, int NT> struct GemmTile {
+    static constexpr int LD = ROWS + 4;
+    static constexpr int REPS = TRANS ? (ROWS * 4 + NT - 1) / NT : (GBK * (ROWS / 4) + NT - 1) / NT;
+    static_assert(REPS >= 1 && REPS <= 2, "tile / thread-count combination not supported");
+    __device__ static __forceinline__ void load(const float *__restrict__ src, int ld, int r0, int rmax, int k0, int kend,
+                                                int tid, float4 (&reg)[2]) {
 #pragma unroll
-    for (int q = 0; q < ROWS / 64; q++) {
-        float4 v = {0.f, 0.f, 0.f, 0.f};
-        if (!TRANS) {
-            const int r = r0 + (tid & (ROWS / 4 - 1)) * 4, k = k0 + tid / (ROWS / 4) + q * 8;
-            if (k < kend) {
-                const float *p = src + (size_t)k * ld + r;
-                if (r + 3 < rmax) v = *reinterpret_cast<const float4 *>(p);
-                else {
-                    if (r < rmax) v.x = p[0];
-                    if (r + 1 < rmax) v.y = p[1];
-                    if (r + 2 < rmax) v.z = p[2];
+        for (int q = 0; q < REPS; q++) {
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (!TRANS) {
+                constexpr int R4 = ROWS / 4, KSTEP = NT / R4;
+                const int r = r0 + (tid % R4) * 4, k = k0 + tid / R4 + q * KSTEP;
+                if (k < kend && tid / R4 + q * KSTEP < GBK) {
+                    const float *p = src + (size_t)k * ld + r;
+                    if (r + 3 < rmax) v = *reinterpret_cast<const float4 *>(p);
+                    else {
+                        if (r < rmax) v.x = p[0];
+                        if (r + 1 < rmax) v.y = p[1];
+                        if (r + 2 < rmax) v.z = p[2];
+                    }
+                }
+            } else {
+                constexpr int RSTEP = NT / 4;
+                const int k = k0 + (tid & 3) * 4, rr = (tid >> 2) + q * RSTEP, r = r0 + rr;
+                if (r < rmax && rr < ROWS) {
+                    const float *p = src + (size_t)r * ld + k;
+                    if (k + 3 < kend) v = *reinterpret_cast<const float4 *>(p);
+                    else {
+                        if (k < kend) v.x = p[0];
+                        if (k + 1 < kend) v.y = p[1];
+                        if (k + 2 < kend) v.z = p[2];
+                    }
                 }
             }
-        } else {
-            const int k = k0 + (tid & 3) * 4, r = r0 + (tid >> 2) + q * 64;
-            if (r < rmax) {
-                const float *p = src + (size_t)r * ld + k;
-                if (k + 3 < kend) v = *reinterpret_cast<const float4 *>(p);
-                else {
-                    if (k < kend) v.x = p[0];
-                    if (k + 1 < kend) v.y = p[1];
-                    if (k + 2 < kend) v.z = p[2];
+            reg[q] = v;
+        }
+    }
+    __device__ static __forceinline__ void store(float *lds, int tid, const float4 (&reg)[2]) {
+#pragma unroll
+        for (int q = 0; q < REPS; q++) {
+            if (!TRANS) {
+                constexpr int R4 = ROWS / 4, KSTEP = NT / R4;
+                const int r = (tid % R4) * 4, k = tid / R4 + q * KSTEP;
+                if (k < GBK) *reinterpret_cast<float4 *>(lds + k * LD + r) = reg[q];
+            } else {
+                constexpr int RSTEP = NT / 4;
+                const int k = (tid & 3) * 4, r = (tid >> 2) + q * RSTEP;
+                if (r < ROWS) {
+                    lds[(k + 0) * LD + r] = reg[q].x;
+                    lds[(k + 1) * LD + r] = reg[q].y;
+                    lds[(k + 2) * LD + r] = reg[q].z;
+                    lds[(k + 3) * LD + r] = reg[q].w;
                 }
             }
         }
-        reg[q] = v;
     }
-}
-template <bool TRANS, int ROWS> __device__ __forceinline__ void gemm_store(float *lds, int tid, const float4 (&reg)[2]) {
-#pragma unroll
-    for (int q = 0; q < ROWS / 64; q++) {
-        if (!TRANS) {
-            const int r = (tid & (ROWS / 4 - 1)) * 4, k = tid / (ROWS / 4) + q * 8;
-            *reinterpret_cast<float4 *>(lds + k * GLD + r) = reg[q];
-        } else {
-            const int k = (tid & 3) * 4, r = (tid >> 2) + q * 64;
-            lds[(k + 0) * GLD + r] = reg[q].x;
-            lds[(k + 1) * GLD + r] = reg[q].y;
-            lds[(k + 2) * GLD + r] = reg[q].z;
-            lds[(k + 3) * GLD + r] = reg[q].w;
-        }
-    }
-}
+};
 
-template <bool TA, bool TB, int NI>
-__global__ __launch_bounds__(256) void k_gemm(int M, int Nn, int K, const float *__restrict__ A, int lda,
-                                              const float *__restrict__ Bm, int ldb, float *__restrict__ C, int ldc,
-                                              int kchunk, size_t slab_stride, int z0) {
-    constexpr int GBN = 64 * NI;
-    __shared__ __attribute__((aligned(16))) float As[GBK * GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[GBK * GLD];
+// MW = 2: 128-row tile, 4 waves; MW = 4: 256-row tile, 8 waves (more FLOP per byte pulled through L2: the
+// K = T products re-read their operands once per tile column/row, and were bandwidth- not MFMA-bound).
+template <bool TA, bool TB, int NI, int MW>
+__global__ __launch_bounds__(128 * MW) void k_gemm(int M, int Nn, int K, const float *__restrict__ A, int lda,
+                                                   const float *__restrict__ Bm, int ldb, float *__restrict__ C, int ldc,
+                                                   int kchunk, size_t slab_stride, int z0) {
+    constexpr int BM = 64 * MW, GBN = 64 * NI, NT = 128 * MW;
+    using TileA = GemmTile<TA, BM, NT>;
+    using TileB = GemmTile<!TB, GBN, NT>;
+    // two LDS stages: tile k+1 is written while tile k is being read, one barrier per k-tile
+    __shared__ __attribute__((aligned(16))) float As[2][GBK * TileA::LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK * TileB::LD];
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int wm = w & 1, wn = w >> 1;
-    const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
-    const int kbeg = (blockIdx.z + z0) * kchunk;
+    const int wm = w % MW, wn = w / MW;
+    // XCD-aware block order (speed only): consecutive block ids are dealt round-robin over the 8 XCDs, each
+    // with its own L2.  Give every XCD one contiguous range of (k-slice, column tile, row tile): with 8
+    // K-slices an XCD then streams only its own slice of both operands instead of all of them.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int total = gridDim.x * gridDim.y * gridDim.z;
+        if ((total & 7) == 0) {
+            const int lin = bx + gridDim.x * (by + gridDim.y * bz);
+            const int nl = (lin & 7) * (total >> 3) + (lin >> 3);
+            bx = nl % gridDim.x;
+            by = (nl / gridDim.x) % gridDim.y;
+            bz = nl / (gridDim.x * gridDim.y);
+        }
+    }
+    const int m0 = bx * BM, n0 = by * GBN;
+    const int kbeg = (bz + z0) * kchunk;
     const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
-    C += (size_t)(blockIdx.z + z0) * slab_stride;
+    C += (size_t)(bz + z0) * slab_stride;
 
     f32x16 acc[2][NI];
 #pragma unroll
@@ -360,31 +393,39 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int Nn, int K, const float 
     float4 ra[2], rb[2];
     // op(A): TA=false -> A is M x K, m contiguous (direct); TA=true -> A stored K x M, k contiguous
     // op(B): TB=true  -> B stored Nn x K, n contiguous (direct); TB=false -> B is K x Nn, k contiguous
-    gemm_load<TA, GBM>(A, lda, m0, M, kbeg, kend, tid, ra);
-    gemm_load<!TB, GBN>(Bm, ldb, n0, Nn, kbeg, kend, tid, rb);
+    TileA::load(A, lda, m0, M, kbeg, kend, tid, ra);
+    TileB::load(Bm, ldb, n0, Nn, kbeg, kend, tid, rb);
+    TileA::store(As[0], tid, ra);
+    TileB::store(Bs[0], tid, rb);
+    __syncthreads();
+    int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-        gemm_store<TA, GBM>(As, tid, ra);
-        gemm_store<!TB, GBN>(Bs, tid, rb);
-        __syncthreads();
-        if (k0 + GBK < kend) {
-            gemm_load<TA, GBM>(A, lda, m0, M, k0 + GBK, kend, tid, ra);
-            gemm_load<!TB, GBN>(Bm, ldb, n0, Nn, k0 + GBK, kend, tid, rb);
+        const bool more = k0 + GBK < kend;
+        if (more) {
+            TileA::load(A, lda, m0, M, k0 + GBK, kend, tid, ra);
+            TileB::load(Bm, ldb, n0, Nn, k0 + GBK, kend, tid, rb);
         }
+        const float *Ac = As[cur], *Bc = Bs[cur];
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 2) {
             const int k = kk + (l >> 5);
             float af[2], bf[NI];
-            af[0] = As[k * GLD + wm * 64 + (l & 31)];
-            af[1] = As[k * GLD + wm * 64 + 32 + (l & 31)];
+            af[0] = Ac[k * TileA::LD + wm * 64 + (l & 31)];
+            af[1] = Ac[k * TileA::LD + wm * 64 + 32 + (l & 31)];
 #pragma unroll
-            for (int ni = 0; ni < NI; ni++) bf[ni] = Bs[k * GLD + wn * 32 * NI + ni * 32 + (l & 31)];
+            for (int ni = 0; ni < NI; ni++) bf[ni] = Bc[k * TileB::LD + wn * 32 * NI + ni * 32 + (l & 31)];
 #pragma unroll
             for (int mi = 0; mi < 2; mi++)
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
         }
+        if (more) {
+            TileA::store(As[cur ^ 1], tid, ra);
+            TileB::store(Bs[cur ^ 1], tid, rb);
+        }
         __syncthreads();
+        cur ^= 1;
     }
     // D[row][col] of the swapped product = C[m = col][n = row]
 #pragma unroll
@@ -411,32 +452,44 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const float *__restrict__ s
     }
 }
 
-// tile width: 128 columns per workgroup unless that leaves most of the 256 CUs idle.  Long-K products
-// are split along K as well, so they tolerate fewer output tiles.
-static int gemm_pick_bn(int M, int Nn, int K) {
-    const int tiles128 = ((M + GBM - 1) / GBM) * ((Nn + 127) / 128);
-    if (K >= 2048) return tiles128 >= 32 ? 128 : 64;
-    return tiles128 >= 192 ? 128 : 64;
+// Tile shape.  Columns: 128 per workgroup unless that leaves most of the 256 CUs idle.  Rows: 256 (8 waves)
+// for the big long-K products, whose cost is the operand bytes re-read per tile; 128 otherwise.
+struct GemmShape {
+    int bm, bn;
+};
+static GemmShape gemm_pick_shape(int M, int Nn, int K) {
+    static const int force_bm = getenv("LSTM_HIP_GEMM_BM") ? atoi(getenv("LSTM_HIP_GEMM_BM")) : 0;
+    const int tiles128 = ((M + 127) / 128) * ((Nn + 127) / 128);
+    GemmShape s;
+    if (K >= 2048) s.bn = tiles128 >= 32 ? 128 : 64;
+    else s.bn = tiles128 >= 192 ? 128 : 64;
+    s.bm = (K >= 2048 && s.bn == 128 && M >= 1024) ? 256 : 128;
+    if (force_bm == 128 || (force_bm == 256 && s.bn == 128)) s.bm = force_bm;
+    return s;
 }
 int gemm_pick_splits(int M, int Nn, int K) {
-    const int bn = gemm_pick_bn(M, Nn, K);
-    const int tiles = ((M + GBM - 1) / GBM) * ((Nn + bn - 1) / bn);
+    const GemmShape sh = gemm_pick_shape(M, Nn, K);
+    const int tiles = ((M + sh.bm - 1) / sh.bm) * ((Nn + sh.bn - 1) / sh.bn);
     int splits = 1;
-    // aim for >= ~512 workgroups, keep >= 8 k-tiles per split
-    while (tiles * splits < 512 && K / (splits * 2) >= 8 * GBK) splits *= 2;
+    // aim for >= ~512 workgroups (256 of the 8-wave ones), keep >= 8 k-tiles per split
+    static const int force = getenv("LSTM_HIP_GEMM_SPLITS") ? atoi(getenv("LSTM_HIP_GEMM_SPLITS")) : 0;
+    if (force > 0 && K >= 2048) return force;
+    const int want = sh.bm == 256 ? 256 : 512;
+    while (tiles * splits < want && K / (splits * 2) >= 8 * GBK) splits *= 2;
     return splits;
 }
 
 static void gemm_launch(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb,
                         float *out, int ldo, int kchunk, size_t stride, int z0, int nz, hipStream_t st) {
-    const int bn = gemm_pick_bn(M, Nn, K);
-    dim3 grid((M + GBM - 1) / GBM, (Nn + bn - 1) / bn, nz);
-#define GEMM_LAUNCH(ta, tb, ni) \
-    hipLaunchKernelGGL((k_gemm<ta, tb, ni>), grid, dim3(256), 0, st, M, Nn, K, A, lda, B, ldb, out, ldo, kchunk, stride, z0)
-#define GEMM_NI(ta, tb)              \
-    do {                             \
-        if (bn == 128) GEMM_LAUNCH(ta, tb, 2); \
-        else GEMM_LAUNCH(ta, tb, 1); \
+    const GemmShape sh = gemm_pick_shape(M, Nn, K);
+    dim3 grid((M + sh.bm - 1) / sh.bm, (Nn + sh.bn - 1) / sh.bn, nz);
+#define GEMM_LAUNCH(ta, tb, ni, mw) \
+    hipLaunchKernelGGL((k_gemm<ta, tb, ni, mw>), grid, dim3(128 * mw), 0, st, M, Nn, K, A, lda, B, ldb, out, ldo, kchunk, stride, z0)
+#define GEMM_NI(ta, tb)                                  \
+    do {                                                 \
+        if (sh.bm == 256) GEMM_LAUNCH(ta, tb, 2, 4);     \
+        else if (sh.bn == 128) GEMM_LAUNCH(ta, tb, 2, 2); \
+        else GEMM_LAUNCH(ta, tb, 1, 2);                  \
     } while (0)
     if (!TA && !TB) GEMM_NI(false, false);
     else if (TA && !TB) GEMM_NI(true, false);
