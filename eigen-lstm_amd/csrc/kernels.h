@@ -105,7 +105,8 @@ void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, size_t u
 // ---- window builder on the device (OV/lstm_eigen_opt/lstm.cc:190-213): x/target rings + flat copies,
 //      cursor advance, and the h/c carry (column 1 -> column 0).  Single workgroup.
 void slide_window(const uint8_t *text, uint64_t len, uint64_t *pos, int32_t *Xr, int32_t *Tr, int32_t *headp,
-                  int32_t *xi, int32_t *ti, float *H, float *C, int S, int B, int N, hipStream_t st);
+                  int32_t *xi, int32_t *ti, float *H, float *C, int S, int B, int N, int stride, int carry_col,
+                  hipStream_t st);
 
 // ---- B = 1 recurrence for the evaluator / sampler (OV/lstm_eigen_class_CUDA/lstm.cc:578-720)
 void eval_bits(const float *P, int N, const uint8_t *text, uint64_t len, double *out_bits_sum, float *scratch,

@@ -997,25 +997,31 @@ __global__ __launch_bounds__(1024) void k_slide_window(const uint8_t *__restrict
                                                        int32_t *__restrict__ Tr, int32_t *__restrict__ headp,
                                                        int32_t *__restrict__ xi, int32_t *__restrict__ ti,
                                                        float *__restrict__ H, float *__restrict__ C, int S, int B,
-                                                       int NB4) {
-    if (blockIdx.x > 0) { // carry: column 0 of the next window is column 1 of this one (opt:205-206)
+                                                       int NB4, int stride, int carry_col) {
+    if (blockIdx.x > 0) { // carry: column 0 of the next window is column `carry_col` of this one (opt:205-206: 1)
+        const size_t src = (size_t)carry_col * NB4;
         for (int i = (blockIdx.x - 1) * blockDim.x + threadIdx.x; i < NB4; i += (gridDim.x - 1) * blockDim.x) {
-            reinterpret_cast<float4 *>(H)[i] = reinterpret_cast<const float4 *>(H)[NB4 + i];
-            reinterpret_cast<float4 *>(C)[i] = reinterpret_cast<const float4 *>(C)[NB4 + i];
+            reinterpret_cast<float4 *>(H)[i] = reinterpret_cast<const float4 *>(H)[src + i];
+            reinterpret_cast<float4 *>(C)[i] = reinterpret_cast<const float4 *>(C)[src + i];
         }
         return;
     }
-    const int head = (*headp + 1) % S;
-    const int last = (head + S - 1) % S, prev = (head + S - 2) % S;
+    int head = *headp;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         uint64_t p = pos[b];
-        const int event = text[p];
-        p++;
-        if (p >= len) p = (uint64_t)S;
+        int hd = head;
+        for (int k = 0; k < stride; k++) { // stride > 1: the segment variant advances several bytes per window
+            hd = (hd + 1) % S;
+            const int last = (hd + S - 1) % S, prev = (hd + S - 2) % S;
+            const int event = text[p];
+            p++;
+            if (p >= len) p = (uint64_t)S;
+            Tr[last * B + b] = event;
+            Xr[last * B + b] = Tr[prev * B + b];
+        }
         pos[b] = p;
-        Tr[last * B + b] = event;
-        Xr[last * B + b] = Tr[prev * B + b];
     }
+    head = (head + stride) % S;
     __syncthreads();
     for (int i = threadIdx.x; i < S * B; i += blockDim.x) {
         const int t = i / B, b = i - t * B;
@@ -1027,12 +1033,13 @@ __global__ __launch_bounds__(1024) void k_slide_window(const uint8_t *__restrict
     if (threadIdx.x == 0) *headp = head;
 }
 void slide_window(const uint8_t *text, uint64_t len, uint64_t *pos, int32_t *Xr, int32_t *Tr, int32_t *headp,
-                  int32_t *xi, int32_t *ti, float *H, float *C, int S, int B, int N, hipStream_t st) {
+                  int32_t *xi, int32_t *ti, float *H, float *C, int S, int B, int N, int stride, int carry_col,
+                  hipStream_t st) {
     const int nb4 = N * B / 4;
     int copy_blocks = (nb4 + 1023) / 1024;
     if (copy_blocks > 32) copy_blocks = 32;
     hipLaunchKernelGGL(k_slide_window, dim3(1 + copy_blocks), dim3(1024), 0, st, text, len, pos, Xr, Tr, headp, xi, ti, H,
-                       C, S, B, nb4);
+                       C, S, B, nb4, stride, carry_col);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -112,6 +112,7 @@ struct lstm_hip_ctx {
     uint64_t text_len = 0;
     uint64_t *pos = nullptr;
     int32_t global_B = 0;
+    int stride = 1, carry_col = 1; // window advance per iteration and the column that becomes the carry
     bool fwd_done = false;
     bool dby_done = false;       // dby already produced by the loss launch of this window
     bool persistent = false;     // default engine; false = one launch per timestep
@@ -686,6 +687,14 @@ int lstm_hip_get_cursors(lstm_hip_t *h, uint64_t *pos) {
     HIP_TRY(hipStreamSynchronize(h->st));
     return 0;
 }
+int lstm_hip_set_stride(lstm_hip_t *h, int32_t stride, int32_t carry_col) {
+    if (!h) return fail(LSTM_HIP_EINVAL, "null handle");
+    if (stride < 1 || stride >= h->cfg.S || carry_col < 0 || carry_col >= h->cfg.S)
+        return fail(LSTM_HIP_EINVAL, "set_stride: need 1 <= stride < S and 0 <= carry_col < S (got %d, %d)", stride, carry_col);
+    h->stride = stride;
+    h->carry_col = carry_col;
+    return 0;
+}
 int lstm_hip_set_global_batch(lstm_hip_t *h, int32_t global_B) {
     if (!h || global_B < h->cfg.B) return fail(LSTM_HIP_EINVAL, "set_global_batch: %d < local B", global_B);
     h->global_B = global_B;
@@ -711,7 +720,7 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
     }
     for (int64_t i = 0; i < count; i++) {
         RUN(K_SLIDE, slide_window(h->text, h->text_len, h->pos, h->Xr, h->Tr, h->head, h->xi, h->ti, h->H, h->C,
-                                  h->cfg.S, h->cfg.B, h->cfg.N, h->st));
+                                  h->cfg.S, h->cfg.B, h->cfg.N, h->stride, h->carry_col, h->st));
         int rc = 0;
         if ((rc = do_forward(h))) return rc;
         RUN(K_LOSS, loss_reduce(h->colloss, h->cfg.S - 1, h->cfg.B, h->global_B, h->d_losses + i, h->dby_part,

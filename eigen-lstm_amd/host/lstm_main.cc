@@ -5,7 +5,7 @@
 //   lstm <text file> <hidden> <seq> <batch> <lr> [options]        (the reference's knobs, R/lstm.cc:53-63)
 //   lstm --data F --hidden N --seq S --batch B --lr LR [--epochs E] [--seed K] [--gpus G]
 //        [--windows W] [--sample C] [--lr-warmup-windows X] [--save PREFIX] [--load PREFIX]
-//        [--eval-file F] [--fast-math] [--step-kernels] [--quiet]
+//        [--eval-file F] [--stride K] [--forget-bias V] [--fast-math] [--step-kernels] [--quiet]
 //
 // stdout follows the reference: "Read N bytes (file)" (R/lstm.cc:398), the carriage-return progress
 // line (OV/lstm_eigen_opt/lstm.cc:320-331), the epoch summary (R/lstm.cc:284-291: GFLOP uses 2^30,
@@ -44,6 +44,8 @@ struct Options {
     long windows = -1;        // cap on windows per epoch (-1: length - S, R/lstm.cc:151)
     int sample = 1000;        // R/lstm.cc:295
     long lr_warmup = 0;
+    int stride = 1;           // bytes per window per stream (lstm_segment.cc: S/2)
+    double forget_bias = 0.0; // OV/lstm_eigen_class_batch/lstm.cc:81 uses 1
     std::string save, load, eval_file;
     unsigned flags = 0;
     bool quiet = false;
@@ -162,6 +164,8 @@ Options parse(int argc, char **argv) {
         else if (a == "--windows") o.windows = atol(val().c_str());
         else if (a == "--sample") o.sample = atoi(val().c_str());
         else if (a == "--lr-warmup-windows") o.lr_warmup = atol(val().c_str());
+        else if (a == "--stride") o.stride = atoi(val().c_str());
+        else if (a == "--forget-bias") o.forget_bias = atof(val().c_str());
         else if (a == "--save") o.save = val();
         else if (a == "--load") o.load = val();
         else if (a == "--eval-file") o.eval_file = val();
@@ -170,7 +174,8 @@ Options parse(int argc, char **argv) {
         else if (a == "--quiet") o.quiet = true;
         else if (a == "-h" || a == "--help") {
             printf("usage: lstm <text file> <hidden> <seq> <batch> <lr> [--epochs E --seed K --gpus G --windows W --sample C\n"
-                   "            --lr-warmup-windows X --save PREFIX --load PREFIX --eval-file F --fast-math --step-kernels --quiet]\n");
+                   "            --lr-warmup-windows X --save PREFIX --load PREFIX --eval-file F --stride K --forget-bias V\n"
+                   "            --fast-math --step-kernels --quiet]\n");
             exit(0);
         } else if (a.rfind("--", 0) == 0) die("unknown option " + a);
         else pos.push_back(a);
@@ -215,6 +220,7 @@ int run_rank(const Options &o, int rank, int up, int down) {
         rng.randn(P.data() + bl[0].off, 4 * N, M, 0.0, 0.01);
         rng.randn(P.data() + bl[1].off, 4 * N, N, 0.0, 0.01);
         rng.randn(P.data() + bl[3].off, M, N, 0.0, 0.01);
+        for (int j = 0; j < N; j++) P[bl[2].off + 2 * N + j] = (float)o.forget_bias; // f-gate bias
     }
     if (!o.load.empty()) {
         if (load_params(o.load, P, N, M)) {
@@ -229,9 +235,10 @@ int run_rank(const Options &o, int rank, int up, int down) {
     for (int b = 0; b < Bl; b++) pos[b] = (uint64_t)S + ((uint64_t)(rank * Bl + b) * (length - S)) / (uint64_t)o.B;
     CK(lstm_hip_set_cursors(h, pos.data()));
     CK(lstm_hip_reset_window(h));
+    if (o.stride > 1) CK(lstm_hip_set_stride(h, o.stride, o.stride - 1)); // segment variant: carry from column seg-1
 
     const double flops_per_iteration = count_flops(M, N, S, o.B);
-    const long windows_per_epoch = (o.windows > 0) ? o.windows : (long)(length - S);
+    const long windows_per_epoch = (o.windows > 0) ? o.windows : (long)((length - S + o.stride - 1) / o.stride);
     long done_windows = 0;
     std::vector<float> hs((size_t)N * o.B), cs((size_t)N * o.B);
     std::vector<double> losses;

@@ -48,7 +48,7 @@ SYMBOLS = [
     "lstm_hip_set_window", "lstm_hip_slide_state", "lstm_hip_forward", "lstm_hip_loss", "lstm_hip_backward",
     "lstm_hip_adagrad", "lstm_hip_comm_unique_id", "lstm_hip_comm_init", "lstm_hip_allreduce_grads",
     "lstm_hip_set_text", "lstm_hip_set_cursors", "lstm_hip_get_cursors", "lstm_hip_reset_window",
-    "lstm_hip_get_window", "lstm_hip_train_windows", "lstm_hip_set_global_batch", "lstm_hip_eval_bits",
+    "lstm_hip_get_window", "lstm_hip_train_windows", "lstm_hip_set_global_batch", "lstm_hip_set_stride", "lstm_hip_eval_bits",
     "lstm_hip_sample", "lstm_hip_synchronize", "lstm_hip_set_profiling", "lstm_hip_kernel_stat_count",
     "lstm_hip_kernel_stat", "lstm_hip_reset_kernel_stats", "lstm_hip_device_info", "lstm_hip_debug_stamps",
 ]
@@ -197,6 +197,9 @@ class Lstm:
     def allreduce_grads(self):
         _chk(self.lib.lstm_hip_allreduce_grads(self._h))
 
+    def set_stride(self, stride, carry_col=1):
+        _chk(self.lib.lstm_hip_set_stride(self._h, stride, carry_col))
+
     def set_global_batch(self, gb):
         _chk(self.lib.lstm_hip_set_global_batch(self._h, gb))
 
@@ -314,12 +317,15 @@ class MT19937Normal:
         return np.ascontiguousarray((mean + std * z).astype(np.float32).T)
 
 
-def init_params(rng, N, M=VOCAB):
-    """R/lstm.cc:113-119: W, U, Why ~ N(0, 0.01) in that order, b = by = 0; flat block."""
+def init_params(rng, N, M=VOCAB, forget_bias=0.0):
+    """R/lstm.cc:113-119: W, U, Why ~ N(0, 0.01) in that order, b = by = 0; flat block.
+    forget_bias = 1 reproduces the later variants' b[2N:3N] = 1 (OV/lstm_eigen_class_batch/lstm.cc:81)."""
     W = rng.randn(4 * N, M, 0.0, 0.01)
     U = rng.randn(4 * N, N, 0.0, 0.01)
     Why = rng.randn(M, N, 0.0, 0.01)
-    return np.concatenate([W.ravel(), U.ravel(), np.zeros(4 * N, np.float32), Why.ravel(), np.zeros(M, np.float32)])
+    b = np.zeros(4 * N, np.float32)
+    b[2 * N:3 * N] = forget_bias
+    return np.concatenate([W.ravel(), U.ravel(), b, Why.ravel(), np.zeros(M, np.float32)])
 
 
 def initial_cursors(length, S, B, stream0=0, streams_total=None):

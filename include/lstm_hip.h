@@ -127,6 +127,10 @@ int lstm_hip_get_cursors(lstm_hip_t *h, uint64_t *pos);
 int lstm_hip_reset_window(lstm_hip_t *h);
 int lstm_hip_get_window(lstm_hip_t *h, int32_t *xi, int32_t *ti);
 int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, double *losses, float *elapsed_ms);
+/* window stride variants (OV/lstm_eigen_class_batch/lstm_segment.cc:110,130,183-187): train_windows advances every
+ * stream by `stride` bytes per iteration (default 1, the root file) and takes the carry h[0],c[0] from column
+ * `carry_col` of the previous window (default 1; the segment variant uses stride = S/2, carry_col = S/2 - 1). */
+int lstm_hip_set_stride(lstm_hip_t *h, int32_t stride, int32_t carry_col);
 /* global batch the loss is divided by (defaults to B; set by the host when streams are sharded) */
 int lstm_hip_set_global_batch(lstm_hip_t *h, int32_t global_B);
 

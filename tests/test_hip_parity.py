@@ -319,3 +319,43 @@ def test_rccl_path_with_a_single_rank_communicator():
     l0, p0 = run(False)
     l1, p1 = run(True)
     assert np.array_equal(l0, l1) and np.array_equal(p0, p1)
+
+
+def test_stride_variant_matches_oracle(oracle32):
+    """Window stride > 1 (OV/lstm_eigen_class_batch/lstm_segment.cc:110,130,183-187): every stream advances
+    `stride` bytes per window and the carry comes from column stride-1.  Lock-step against the oracle's slide
+    applied `stride` times with the same carry rule; indices and cursors bit-exact."""
+    import lstm_hip
+    N, S, B, stride, windows, lr = 64, 10, 16, 5, 12, 0.05
+    text = _synthetic_text(300, seed=21)
+    tr = oracle32.trainer(text, N, S, B, lr=lr, seed=4)
+    tr.epoch_reset()
+    L = lstm_hip.Lstm(N, S, B)
+    L.set_text(text)
+    L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
+    L.reset_window()
+    L.set_stride(stride, stride - 1)
+    for w in range(windows):
+        L.set_params(tr.params.copy())
+        L.set_params(tr.mem.copy(), lstm_hip.P_MEM)
+        for t in range(S):
+            L.set_state(t, tr.h[t], tr.c[t])
+        got = L.train_windows(1, lr)[0]
+        # oracle: remember the carry column, slide `stride` times (indices, cursors), then apply the carry rule
+        hc, cc = tr.h[stride - 1].copy(), tr.c[stride - 1].copy()
+        for _ in range(stride):
+            tr.slide()
+        tr.h[0][:] = hc
+        tr.c[0][:] = cc
+        fw = oracle32.forward(N, 256, S, B, tr.params, tr.xi, tr.ti, tr.h[0], tr.c[0])
+        d = oracle32.backward(N, 256, S, B, tr.params, tr.xi, tr.ti, fw)
+        tr.h[:] = fw["h"]
+        tr.c[:] = fw["c"]
+        oracle32.adagrad(tr.params, d, tr.mem, lr)
+        want = fw["loss_bits"]
+        assert abs(got - want) <= LOSS_TOL * (S - 1), (w, got, want)
+        xi, ti = L.get_window()
+        assert np.array_equal(xi, tr.xi) and np.array_equal(ti, tr.ti), w
+        mask = np.abs(d) > 1e-3 * np.abs(d).max()
+        assert np.abs(L.get_params()[mask] - tr.params[mask]).max() <= 2e-4 * lr + 1e-6, w
+    L.close()
