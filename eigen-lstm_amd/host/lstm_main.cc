@@ -252,6 +252,7 @@ int run_rank(const Options &o, int rank, int up, int down) {
             CK(lstm_hip_set_state(h, t, hs.data() + (size_t)rank * Bl * N, cs.data() + (size_t)rank * Bl * N));
         }
         double epoch_loss = 0.0;
+        long nan_windows = 0;
         const double t0 = now();
         double tf = t0;
         for (long i = 0; i < windows_per_epoch;) {
@@ -263,8 +264,10 @@ int run_rank(const Options &o, int rank, int up, int down) {
             }
             losses.resize(chunk);
             CK(lstm_hip_train_windows(h, chunk, lr, losses.data(), nullptr));
-            for (double v : losses)
+            for (double v : losses) {
                 if (!std::isnan(v)) epoch_loss += v; // NaN guard as OV/lstm_eigen_class_CUDA/lstm.cc:325-326
+                else nan_windows++;
+            }
             i += chunk;
             done_windows += chunk;
             if (lead && !o.quiet) {
@@ -288,6 +291,9 @@ int run_rank(const Options &o, int rank, int up, int down) {
                    epoch_loss / ((double)S * (double)(windows_per_epoch + S))); // R/lstm.cc:290: loss/(S*length)
             printf("chars/s through fwd+BPTT = %.1f (%ld windows, %d GPU%s)\n", chars / epoch_time, windows_per_epoch, o.gpus,
                    o.gpus > 1 ? "s" : "");
+            if (nan_windows > 0) // the reference skips NaN losses silently; the unshifted softmax (R/lstm.cc:199) overflows when lr is too large
+                printf("!!!! %ld of %ld windows had a NaN loss (skipped in the average): lower --lr or use --lr-warmup-windows\n",
+                       nan_windows, windows_per_epoch);
             if (!o.eval_file.empty()) {
                 std::vector<uint8_t> ev = rawread(o.eval_file);
                 double bits = 0.0;
