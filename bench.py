@@ -9,8 +9,10 @@ the flat gradient block], Adagrad -- everything the reference's i-loop does per 
 quoted on): hidden 512, window 100, batch 64 per GPU, fp32.  The corpus is synthetic (1e6 bytes drawn
 with enwik6's order-0 byte statistics): /root/reference does not exist on the GPU box and the
 throughput is content-independent.  For N > 1 the driver launches one rank per GPU with
-torch.distributed.run; torch is used ONLY as rendezvous plumbing (gloo: barrier, unique-id
-broadcast, max-over-ranks) -- the data path is the C-ABI library and RCCL inside it.
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT from the env).  The ranks exchange only
+the RCCL id, barriers and a few doubles, over dp.Rendezvous (plain sockets): the GPU processes do not import
+torch, so the library's HIP runtime and RCCL are the only copies mapped.  The data path is the C-ABI library
+and RCCL inside it.
 
 Prints ONE JSON line on rank 0 (see the task contract), including
   roofline     : the dominant kernel's algorithmic FLOP per launch / its HIP-event-timed duration
@@ -26,6 +28,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "eigen-lstm_amd"))
+if os.environ.get("LSTM_BENCH_FAKE_GPU") == "1":  # CPU test of the multi-rank plumbing only (tests/fake_gpu)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fake_gpu"))
 
 METRIC = "chars/sec fwd+BPTT, enwik6 H=512 S=100 B=64, 1/2/4/8 GPU"
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
@@ -38,8 +42,9 @@ def synthetic_text(n_bytes, seed=0):
     return np.random.RandomState(seed).choice(256, size=n_bytes, p=p).astype(np.uint8)
 
 
-def kernel_flops(N, S, B, M=256):
-    """algorithmic FLOP per launch of each MFMA kernel (one-hot structure exploited)."""
+def kernel_flops(N, S, B, M=256, fused=True):
+    """algorithmic FLOP per launch of each MFMA kernel (one-hot structure exploited).
+    fused: the backward recurrence also computes Why^T*dy and dy*h^T (R/lstm.cc:226,228) itself."""
     T = (S - 1) * B
     return {
         "fwd_step": 2.0 * 4 * N * N * B,                       # U * h_prev           R/lstm.cc:176
@@ -49,7 +54,7 @@ def kernel_flops(N, S, B, M=256):
         "gemm_dWhy": 2.0 * M * N * T,                          # dy * h^T             :226
         "gemm_dU": 2.0 * 4 * N * N * T,                        # dg * h_prev^T        :250
         "fwd_persistent": 2.0 * 4 * N * N * B * (S - 1),
-        "bwd_persistent": 2.0 * 4 * N * N * B * (S - 2),
+        "bwd_persistent": 2.0 * 4 * N * N * B * (S - 2) + (4.0 * M * N * T if fused else 0.0),
     }
 
 
@@ -112,10 +117,7 @@ def main():
     import lstm_hip
 
     N, S, B, lr = args.hidden, args.seq, args.batch, args.lr
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # rendezvous plumbing only; no torch.cuda use
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rdzv = dp.Rendezvous(rank, world, tag=os.environ.get("MASTER_PORT", "0") + "_" + os.environ.get("TORCHELASTIC_RUN_ID", "0"))
 
     text = synthetic_text(1_000_000, seed=0)
     L = lstm_hip.Lstm(N, S, B, device=local_rank, flags=args.flags)
@@ -127,14 +129,11 @@ def main():
     L.set_cursors(dp.cursors(len(text), S, rank, world, world * B))  # rank r owns streams [r*B, (r+1)*B)
     L.set_global_batch(world * B)
     if world > 1:
-        ids = [lstm_hip.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        L.comm_init(ids[0], world, rank)
+        L.comm_init(rdzv.broadcast(lstm_hip.comm_unique_id() if rank == 0 else None), world, rank)
 
     def barrier():
         L.synchronize()
-        if dist is not None:
-            dist.barrier()
+        rdzv.barrier()
 
     L.train_windows(args.warmup, lr, want_losses=False)
     barrier()
@@ -143,14 +142,10 @@ def main():
     L.synchronize()
     barrier()
     wall = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tmax = torch.tensor([wall], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
-        lsum = torch.tensor(losses, dtype=torch.float64)
-        dist.all_reduce(lsum, op=dist.ReduceOp.SUM)
-        losses = lsum.numpy()
+    if world > 1:
+        gathered = rdzv.allgather((wall, losses))
+        wall = max(g[0] for g in gathered)                      # MAX over ranks
+        losses = np.sum([g[1] for g in gathered], axis=0)       # each rank's share of the global-batch loss
     if not np.all(np.isfinite(losses)):
         sys.exit(f"non-finite loss in the timed region: {losses[:5]}")
 
@@ -167,7 +162,7 @@ def main():
         L.set_profiling(False)
         kstats = {k: v for k, v in L.kernel_stats().items() if v[0] > 0}
     if rank == 0:
-        fl = kernel_flops(N, S, B)
+        fl = kernel_flops(N, S, B, fused=not (args.flags & 64) and N <= 512 and B % 8 == 0 and B > 8)
         mf = {k: v for k, v in kstats.items() if k in fl}
         if mf:
             dom = max(mf, key=lambda k: mf[k][1])
@@ -185,7 +180,8 @@ def main():
             "metric": METRIC, "value": round(value, 1), "unit": "chars/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (1e6 bytes, enwik6 order-0 byte statistics; random-init weights, seed 1)",
+            "data": ("FAKE GPU (plumbing test, not a measurement) " if getattr(lstm_hip, "FAKE", False) else "")
+                    + "synthetic (1e6 bytes, enwik6 order-0 byte statistics; random-init weights, seed 1)",
             "config": {"workload": f"enwik6-shaped text, hidden={N} seq={S} batch={B}/GPU (global {B * world}), fp32, "
                                    "stride-1 windows, Adagrad lr=%g" % lr,
                        "parallelism": f"dp{world}" if world > 1 else "single",
@@ -199,9 +195,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(N, S, B, text, lr)
         print(json.dumps(out), flush=True)
     L.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rdzv.barrier()
+    rdzv.close()
 
 
 if __name__ == "__main__":

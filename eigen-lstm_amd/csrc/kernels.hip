@@ -406,20 +406,25 @@ __global__ __launch_bounds__(128 * MW) void k_gemm(int M, int Nn, int K, const f
             TileB::load(Bm, ldb, n0, Nn, k0 + GBK, kend, tid, rb);
         }
         const float *Ac = As[cur], *Bc = Bs[cur];
+        // every fragment of the k-tile is read before its first MFMA (one exposed LDS latency per tile; read
+        // step by step, each group of four MFMAs waited on its own ds_reads: lgkmcnt(0) eight times a tile)
+        float af[GBK / 2][2], bf[GBK / 2][NI];
 #pragma unroll
-        for (int kk = 0; kk < GBK; kk += 2) {
-            const int k = kk + (l >> 5);
-            float af[2], bf[NI];
-            af[0] = Ac[k * TileA::LD + wm * 64 + (l & 31)];
-            af[1] = Ac[k * TileA::LD + wm * 64 + 32 + (l & 31)];
+        for (int s2 = 0; s2 < GBK / 2; s2++) {
+            const int k = 2 * s2 + (l >> 5);
+            af[s2][0] = Ac[k * TileA::LD + wm * 64 + (l & 31)];
+            af[s2][1] = Ac[k * TileA::LD + wm * 64 + 32 + (l & 31)];
 #pragma unroll
-            for (int ni = 0; ni < NI; ni++) bf[ni] = Bc[k * TileB::LD + wn * 32 * NI + ni * 32 + (l & 31)];
+            for (int ni = 0; ni < NI; ni++) bf[s2][ni] = Bc[k * TileB::LD + wn * 32 * NI + ni * 32 + (l & 31)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < GBK / 2; s2++)
 #pragma unroll
             for (int mi = 0; mi < 2; mi++)
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-        }
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s2][ni], af[s2][mi], acc[mi][ni], 0, 0, 0);
         if (more) {
             TileA::store(As[cur ^ 1], tid, ra);
             TileB::store(Bs[cur ^ 1], tid, rb);

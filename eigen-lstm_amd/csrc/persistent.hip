@@ -79,8 +79,10 @@ __device__ __forceinline__ void st_sc1(float4 f, __amdgpu_buffer_rsrc_t r, int b
 // wave-level wait until all `n_prod` producers (sharded by id & 7) have arrived at `cp`.
 // Returns false on time-out / abort.  Called by one whole wave.
 // Counters are never reset: launch number `epoch` (1, 2, ...) waits for epoch * (arrivals per launch).
-__device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, unsigned epoch, unsigned *abortp, int lane) {
+__device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, unsigned epoch, unsigned *abortp, int lane,
+                                              int first_delay = 0) {
     const unsigned expect = lane < 8 ? epoch * (unsigned)((n_prod - lane + 7) / 8) : 0u;
+    for (int i = 0; i < first_delay; i++) __builtin_amdgcn_s_sleep(1); // 64 cycles each
     for (int spins = 0;; spins++) {
         unsigned v = 0;
         if (lane < 8) v = __hip_atomic_load(cp + lane * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
     // group is a burst of device-scope loads (all its workgroups pull the same h_{t-1}); offsetting
     // group g by g/NG of a step keeps the groups out of each other's burst.
     if (!STAMP)
-        for (int i = 0; i < g * stagger; i++) __builtin_amdgcn_s_sleep(32);
+        for (int i = 0; i < g * (stagger & 255); i++) __builtin_amdgcn_s_sleep(32);
 
     for (int t = 1; t < S; t++) {
         float wx[4] = {0.f, 0.f, 0.f, 0.f};
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
             }
             if (t > 1) {
                 const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * 8 * CNT_STRIDE;
-                if (!wait_arrivals(cp, NB, epoch, abortp, l) && l == 0) s_abort = 1;
+                if (!wait_arrivals(cp, NB, epoch, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
             }
         }
         __syncthreads();
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     }
     __syncthreads();
     if (!STAMP)
-        for (int i = 0; i < g * stagger; i++) __builtin_amdgcn_s_sleep(32); // see k_fwd_persistent
+        for (int i = 0; i < g * (stagger & 255); i++) __builtin_amdgcn_s_sleep(32); // see k_fwd_persistent
 
     // sync point of the EW elementwise waves only (LDS counter; LDS operations of a wave complete in order)
     auto pair_sync = [&]() {
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
         if (FUSE && w >= 4 && t >= 2) output_layer_fetch(t - 1);
         if (has_next && w == 0) {
             const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * 8 * CNT_STRIDE;
-            if (!wait_arrivals(cpn, NBK, epoch, abortp, l) && l == 0) s_abort = 1;
+            if (!wait_arrivals(cpn, NBK, epoch, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
         }
         __syncthreads();
         if (s_abort) return;

@@ -71,3 +71,47 @@ def test_shard_helpers():
     with pytest.raises(ValueError):
         dp.shard(0, 3, 64)
     assert dp.local_loss_to_global(8.0, 16, 64) == 2.0
+
+
+def _rdzv_worker(rank, world, tag, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "eigen-lstm_amd"))
+    import dp
+    r = dp.Rendezvous(rank, world, tag, timeout=60.0)
+    got = r.allgather((rank, rank * 1.5))
+    b = r.broadcast(b"x" * 128 if rank == 0 else None)
+    r.barrier()
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([g[1] for g in got] + [len(b)]))
+    r.close()
+
+
+def test_socket_rendezvous_used_by_the_bench(tmp_path):
+    """bench.py's N>1 plumbing (dp.Rendezvous: rank-0 star over TCP, port published through a file)."""
+    import torch.multiprocessing as mp
+    world = 4
+    mp.spawn(_rdzv_worker, args=(world, f"test_{os.getpid()}", str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        v = np.load(tmp_path / f"r{r}.npy")
+        assert list(v) == [0.0, 1.5, 3.0, 4.5, 128.0]
+
+
+def test_bench_multi_rank_plumbing_under_torchrun():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` exactly as the driver launches it, with
+    the GPU library replaced by tests/fake_gpu: rendezvous, RCCL-id broadcast, barriers, max-over-ranks, ONE JSON
+    line on rank 0 with whole-job throughput."""
+    import json
+    import subprocess
+    env = dict(os.environ, LSTM_BENCH_FAKE_GPU="1")
+    port = 29700 + (os.getpid() % 200)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["unit"] == "chars/s"
+    assert d["config"]["parallelism"] == "dp2" and "FAKE GPU" in d["data"]
+    # whole-job aggregate: both ranks' characters over the slowest rank's time
+    assert abs(d["value"] - 99 * 64 * 5 * 2 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-3
+    assert d["loss_first_last"] == [2.0, 2.0]  # sum over ranks of each rank's share
