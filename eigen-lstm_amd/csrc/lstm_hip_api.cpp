@@ -44,7 +44,7 @@ enum KernelId {
 };
 const char *const kKernelNames[K_COUNT] = {
     "pack_U", "fwd_step", "gemm_Y", "softmax_loss_dy", "loss_reduce", "gemm_DHy", "bwd_step", "gemm_dWhy", "gemm_dU",
-    "dW_db", "dby_finish", "adagrad", "slide", "allreduce", "fwd_persistent", "bwd_persistent"};
+    "dW_db", "loss_dby", "adagrad", "slide", "allreduce", "fwd_persistent", "bwd_persistent"};
 
 // ---- RCCL, loaded on first use so single-GPU users never touch it --------------------------
 struct UniqueId {
