@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -112,6 +113,7 @@ struct lstm_hip_ctx {
     uint64_t text_len = 0;
     uint64_t *pos = nullptr;
     int32_t global_B = 0;
+    lstm_hip_ctx *eval_h = nullptr; // internal B = 1 handle used by lstm_hip_eval_bits
     int stride = 1, carry_col = 1; // window advance per iteration and the column that becomes the carry
     bool fwd_done = false;
     bool dby_done = false;       // dby already produced by the loss launch of this window
@@ -495,6 +497,7 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
 int lstm_hip_destroy(lstm_hip_t *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
+    if (h->eval_h) (void)lstm_hip_destroy(h->eval_h);
     (void)hipStreamSynchronize(h->st);
     if (h->st2) (void)hipStreamSynchronize(h->st2);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
@@ -743,17 +746,62 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
     return check_abort(h);
 }
 
+// test(), OV/lstm_eigen_class_CUDA/lstm.cc:661-720: one stream from h = c = 0, bits/char over the text.
+// Where the persistent forward recurrence exists for this hidden size, the text is run through it in
+// chunks on an internal B = 1 handle (the carry moves from the last column of a chunk to column 0 of the
+// next); otherwise by the single-workgroup kernel.
 int lstm_hip_eval_bits(lstm_hip_t *h, const uint8_t *text, size_t len, double *bits_per_char) {
     CHECK(h);
     if (!text || len < 2 || !bits_per_char) return fail(LSTM_HIP_EINVAL, "eval_bits: need >= 2 bytes and an output pointer");
-    uint8_t *d_text = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_text, len));
-    HIP_TRY(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, h->st));
-    eval_bits(h->P, h->cfg.N, d_text, len, h->d_loss, nullptr, h->st);
-    double sum = 0.0;
-    HIP_TRY(hipMemcpyAsync(&sum, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->st));
+    const int N = h->cfg.N;
+    if (!h->persistent || (h->cfg.flags & LSTM_HIP_STEP_KERNELS)) {
+        uint8_t *d_text = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_text, len));
+        HIP_TRY(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, h->st));
+        eval_bits(h->P, N, d_text, len, h->d_loss, nullptr, h->st);
+        double sum = 0.0;
+        HIP_TRY(hipMemcpyAsync(&sum, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->st));
+        HIP_TRY(hipStreamSynchronize(h->st));
+        HIP_TRY(hipFree(d_text));
+        *bits_per_char = sum / (double)(len - 1);
+        return 0;
+    }
     HIP_TRY(hipStreamSynchronize(h->st));
-    HIP_TRY(hipFree(d_text));
+    const int Se = 129; // 128 characters per chunk
+    if (!h->eval_h) {
+        lstm_hip_config c = h->cfg;
+        c.S = Se;
+        c.B = 1;
+        c.flags = (h->cfg.flags & LSTM_HIP_FAST_MATH) | LSTM_HIP_NO_FUSED_GRADS;
+        int rc = lstm_hip_create(&c, &h->eval_h);
+        if (rc) return rc;
+    }
+    lstm_hip_ctx *e = h->eval_h;
+    HIP_TRY(hipMemcpy(e->P, h->P, sizeof(float) * h->pl.total, hipMemcpyDeviceToDevice));
+    e->packed = false;
+    HIP_TRY(hipMemset(e->H, 0, sizeof(float) * N)); // h = c = 0 (reset_std = 0, lstm.cc:45,676-677)
+    HIP_TRY(hipMemset(e->C, 0, sizeof(float) * N));
+    std::vector<int32_t> xi(Se), ti(Se);
+    double sum = 0.0;
+    for (size_t pos = 0; pos + 1 < len; pos += Se - 1) {
+        const size_t steps = std::min<size_t>(Se - 1, len - 1 - pos);
+        xi[0] = ti[0] = -1;
+        for (int t = 1; t < Se; t++) {
+            const bool in = (size_t)t <= steps;
+            xi[t] = in ? (int32_t)text[pos + t - 1] : -1; // past the end: empty columns, no loss
+            ti[t] = in ? (int32_t)text[pos + t] : -1;
+        }
+        int rc = lstm_hip_set_window(e, xi.data(), ti.data());
+        if (rc) return rc;
+        if ((rc = do_forward(e))) return rc;
+        double part = 0.0;
+        if ((rc = lstm_hip_loss(e, &part))) return rc;
+        sum += part;
+        // carry: the state after the chunk's last real character becomes column 0
+        HIP_TRY(hipMemcpyAsync(e->H, e->H + (size_t)steps * N, sizeof(float) * N, hipMemcpyDeviceToDevice, e->st));
+        HIP_TRY(hipMemcpyAsync(e->C, e->C + (size_t)steps * N, sizeof(float) * N, hipMemcpyDeviceToDevice, e->st));
+    }
+    HIP_TRY(hipStreamSynchronize(e->st));
     *bits_per_char = sum / (double)(len - 1);
     return 0;
 }

@@ -359,3 +359,54 @@ def test_stride_variant_matches_oracle(oracle32):
         mask = np.abs(d) > 1e-3 * np.abs(d).max()
         assert np.abs(L.get_params()[mask] - tr.params[mask]).max() <= 2e-4 * lr + 1e-6, w
     L.close()
+
+
+def test_engines_agree_at_the_headline_shape():
+    """BASELINE configs[2] shape: the default engine (persistent recurrences, fused gradient sums) and the
+    per-step engine (separate GEMMs, sorted segment sums) are two independent implementations of the window;
+    they must agree on the loss, the carry and every gradient tensor."""
+    import lstm_hip
+    N, S, B = 512, 100, 64
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=77, scale=0.02, empty=((1, 5), (2, 5)))
+
+    def run(flags):
+        L = lstm_hip.Lstm(N, S, B, flags=flags)
+        L.set_params(P)
+        L.set_state(0, h0, c0)
+        L.set_window(xi, ti)
+        L.forward()
+        loss = L.loss()
+        L.backward()
+        g = L.get_grads()
+        h1, c1 = L.get_state(1)
+        hl, _ = L.get_state(S - 1)
+        L.close()
+        return loss, g, h1, hl
+
+    la, ga, h1a, hla = run(0)
+    lb, gb, h1b, hlb = run(lstm_hip.STEP_KERNELS)
+    assert abs(la - lb) <= 1e-5 * (S - 1)
+    assert gu.max_rel(h1a, h1b) <= 1e-6 and gu.max_rel(hla, hlb) <= 1e-5
+    rep = gu.grads_report(ga, gb, N)
+    assert max(rep.values()) <= 5e-5, rep
+    g = split_params(ga, N)
+    # x is one-hot or empty: db = sum over input bytes of dW + the empty columns' share (two of them here)
+    assert np.abs(g["W"].sum(axis=1) - g["b"][:, 0]).max() <= 1e-2 * np.abs(g["b"]).max()
+
+
+def test_evaluator_through_the_persistent_recurrence(oracle32):
+    """lstm_hip_eval_bits at a hidden size the persistent forward kernel supports: the text is chunked through
+    an internal B = 1 handle; bits/char must match the oracle's test() restatement, also across chunk
+    boundaries (length not a multiple of the chunk) and for a text shorter than one chunk."""
+    import lstm_hip
+    N = 128
+    P, _, _, _, _ = gu.random_case(N, 2, 1, seed=13, scale=0.15)
+    rs = np.random.RandomState(4)
+    for n in (1000, 37):
+        text = rs.randint(32, 127, size=n).astype(np.uint8)
+        L = lstm_hip.Lstm(N, 4, 8)
+        L.set_params(P)
+        got = L.eval_bits(text)
+        L.close()
+        want = oracle32.eval_bits(N, 256, P, text)
+        assert abs(got - want) <= 1e-4, (n, got, want)
