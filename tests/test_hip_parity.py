@@ -26,6 +26,8 @@ CASES = [
     (128, 25, 1, ()),                    # BASELINE configs[0] shape (alice29 N=128 S=25 B=1)
     (256, 50, 32, ()),                   # BASELINE configs[1] shape
     (1024, 4, 16, ()),                   # widest persistent instantiation (BASELINE configs[4] hidden size, fp32)
+    (64, 2, 16, ()),                     # persistent engine with a single timestep
+    (64, 3, 9, ((1, 8),)),               # ... two timesteps, ragged batch
 ]
 
 
@@ -410,3 +412,15 @@ def test_evaluator_through_the_persistent_recurrence(oracle32):
         L.close()
         want = oracle32.eval_bits(N, 256, P, text)
         assert abs(got - want) <= 1e-4, (n, got, want)
+
+
+def test_create_destroy_does_not_leak():
+    """cuLSTM/cuParameters are RAII in the reference (cu_lstm.h:24-42,83-144); the handle must release everything."""
+    import lstm_hip
+    for _ in range(40):
+        L = lstm_hip.Lstm(256, 20, 32)
+        L.close()
+    L = lstm_hip.Lstm(512, 100, 64)  # ~250 MB; would fail if the 40 above had leaked device memory badly
+    L.forward()
+    L.synchronize()
+    L.close()
