@@ -101,6 +101,7 @@ def main():
                     help="Adagrad step; 0.1 (R/lstm.cc:59) overflows the unshifted softmax at hidden=512 batch=64 "
                          "within ~100 windows unless the class_CUDA warm-up (lr=0 for 50*S windows) is used")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--bf16", action="store_true", help="bf16 MFMA in the recurrent products (not the headline dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-windows", type=int, default=3)
     args = ap.parse_args()
@@ -116,6 +117,8 @@ def main():
     import dp
     import lstm_hip
 
+    if args.bf16:
+        args.flags |= 128  # LSTM_HIP_BF16_RECURRENCE
     N, S, B, lr = args.hidden, args.seq, args.batch, args.lr
     rdzv = dp.Rendezvous(rank, world, tag=os.environ.get("MASTER_PORT", "0") + "_" + os.environ.get("TORCHELASTIC_RUN_ID", "0"))
 
@@ -179,7 +182,8 @@ def main():
         out = {
             "metric": METRIC, "value": round(value, 1), "unit": "chars/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 recurrent MFMA (f32 accumulate, f32 elsewhere)" if args.flags & 128 else "f32",
             "data": ("FAKE GPU (plumbing test, not a measurement) " if getattr(lstm_hip, "FAKE", False) else "")
                     + "synthetic (1e6 bytes, enwik6 order-0 byte statistics; random-init weights, seed 1)",
             "config": {"workload": f"enwik6-shaped text, hidden={N} seq={S} batch={B}/GPU (global {B * world}), fp32, "

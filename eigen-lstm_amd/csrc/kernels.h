@@ -56,7 +56,14 @@ void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, uns
 // (bwd_partial_floats(N) floats each) to be folded in group order; H and xi are read as well.
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,
                     const int32_t *xi, float *gpart, const float *Why, const float *dY, unsigned *cnt, unsigned *abortp,
-                    unsigned epoch, int N, int S, int B, int cols, hipStream_t st, unsigned long long *stamps = nullptr);
+                    unsigned epoch, int N, int S, int B, int cols, hipStream_t st, unsigned long long *stamps = nullptr,
+                    unsigned short *DGb = nullptr);
+// bf16 recurrence (N % 128 == 0): bf16 fragment images of U (N*N*8 bytes each), h and dg also kept as bf16
+// hand-off copies Hb [S][B][N], DGb [S][B][4N]; bwd_persistent takes the Ubwd16 image as `Ubwd` and DGb != null
+void pack_U_bf16(const float *U, void *Ufwd16, void *Ubwd16, int N, hipStream_t st);
+void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, float *H, unsigned short *Hb, float *C,
+                         float *G, const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
+                         bool fast, hipStream_t st);
 size_t bwd_partial_floats(int N);
 int bwd_group_cols(int N, int B, int n_cus); // 8 or 16 batch columns per backward workgroup
 

@@ -92,6 +92,10 @@ struct lstm_hip_ctx {
                                // LSTM_HIP_OVERLAP_MASK is set
     int chunk_steps = 0;       // timesteps per follower chunk
     float *slabs_dU = nullptr; // split-K slabs of dU (one per time chunk in overlap mode)
+    bool bf16 = false;         // LSTM_HIP_BF16_RECURRENCE
+    bool packed16 = false;
+    unsigned short *Hb = nullptr, *DGb = nullptr; // bf16 hand-off copies of h and dg
+    void *Ufwd16 = nullptr, *Ubwd16 = nullptr;    // bf16 fragment images of U
     float *gpart = nullptr;    // per-column-group partial [dW|dU|db] blocks of the fused backward recurrence
     bool dhy_done = false;
     int bwd_cols = 16;         // batch columns per backward-recurrence workgroup (8 or 16)
@@ -209,6 +213,15 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
             h->fwd_epoch = 0;
         }
         h->fwd_epoch++;
+        if (h->bf16) {
+            if (!h->packed16) {
+                RUN(K_PACK_U, pack_U_bf16(h->P + h->pl.U, h->Ufwd16, h->Ubwd16, N, h->st));
+                h->packed16 = true;
+            }
+            RUN(K_FWD_PERSIST, fwd_persistent_bf16(h->Ufwd16, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi,
+                                                   h->cnt, h->abortp, h->fwd_epoch, N, S, B, fast, h->st));
+            return 0;
+        }
         RUN(K_FWD_PERSIST, fwd_persistent(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->cnt,
                                           h->abortp, h->fwd_epoch, N, S, B, fast, h->st, h->stamps));
     } else {
@@ -339,6 +352,11 @@ int do_backward(lstm_hip_ctx *h) {
         return 0;
     }
     if (h->persistent) {
+        if (h->bf16)
+            RUN(K_BWD_PERSIST, bwd_persistent(reinterpret_cast<const float4 *>(h->Ubwd16), h->DG, h->DHy, h->G, h->C, h->H,
+                                              h->xi, fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp,
+                                              h->bwd_epoch, N, S, B, 8, h->st, nullptr, h->DGb));
+        else
         RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr,
                                           h->P + h->pl.Why, dY, cb, h->abortp, h->bwd_epoch, N, S, B, h->bwd_cols, h->st,
                                           h->stamps ? h->stamps + (size_t)2 * S * 8 : nullptr));
@@ -383,6 +401,7 @@ int do_allreduce(lstm_hip_ctx *h) {
 int do_adagrad(lstm_hip_ctx *h, double lr) {
     RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd, h->Ubwd, h->st));
     h->packed = true; // the U images were refreshed by the same launch
+    h->packed16 = false;
     return 0;
 }
 
@@ -470,10 +489,20 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
     ALLOC(h->abortp, 4);
     h->persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) && persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount);
     h->bwd_cols = bwd_group_cols(cfg->N, cfg->B, prop.multiProcessorCount);
+    if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) {
+        if (!h->persistent || cfg->N % 128 != 0 || (cfg->flags & LSTM_HIP_GRANULE_HANDOFF) || cfg->N > 1024)
+            return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE needs the persistent engine and N a multiple of 128, <= 1024 (N=%d, B=%d)", cfg->N, cfg->B);
+        h->bf16 = true;
+        h->bwd_cols = 8;
+        ALLOC(h->Hb, S * B * N);
+        ALLOC(h->DGb, S * B * G4);
+        HIP_TRY(hipMalloc(&h->Ufwd16, (size_t)8 * N * N));
+        HIP_TRY(hipMalloc(&h->Ubwd16, (size_t)8 * N * N));
+    }
     if (h->persistent && !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512) // larger N: the dU tiles no longer fit the VGPRs
         ALLOC(h->gpart, (size_t)((B + h->bwd_cols - 1) / h->bwd_cols) * bwd_partial_floats(cfg->N));
     // followers need whole MFMA k-tiles and whole softmax waves per time chunk
-    h->overlap = h->persistent && !(cfg->flags & (LSTM_HIP_NO_OVERLAP | LSTM_HIP_GRANULE_HANDOFF)) && cfg->B % 16 == 0;
+    h->overlap = h->persistent && !(cfg->flags & (LSTM_HIP_NO_OVERLAP | LSTM_HIP_GRANULE_HANDOFF | LSTM_HIP_BF16_RECURRENCE)) && cfg->B % 16 == 0;
     if (const char *e = getenv("LSTM_HIP_OVERLAP_MASK")) h->overlap_mask = atoi(e);
     if (h->overlap && (h->overlap_mask & 4)) {
         // CU-partitioned overlap: the backward recurrence (N/16 * ceil(B/16) workgroups, one per CU) gets the
@@ -502,7 +531,7 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     if (h->st2) (void)hipStreamSynchronize(h->st2);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
-                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->Hg, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
+                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->Hg, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -524,7 +553,7 @@ int lstm_hip_set_params(lstm_hip_t *h, int which, const float *host_block) {
     if (!dst || !host_block) return fail(LSTM_HIP_EINVAL, "set_params: bad block id %d or null pointer", which);
     HIP_TRY(hipMemcpyAsync(dst, host_block, sizeof(float) * h->pl.total, hipMemcpyHostToDevice, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
-    if (which == 0) h->packed = false;
+    if (which == 0) h->packed = h->packed16 = false;
     return 0;
 }
 int lstm_hip_get_params(lstm_hip_t *h, int which, float *host_block) {

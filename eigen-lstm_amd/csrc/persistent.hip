@@ -226,6 +226,176 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 recurrence (LSTM_HIP_BF16_RECURRENCE, BASELINE configs[4]): the operands of U*h_prev are bfloat16
+// (round-to-nearest-even of the fp32 master weights and of the published h), the accumulation is fp32,
+// everything else is the fp32 kernel above.  MFMA 16x16x32 bf16: A[row=l&15][k=8*(l>>4)+j],
+// B[k=8*(l>>4)+j][col=l&15], j = 0..7; one lane-fragment is 16 bytes.  N = 128*NKS.
+//   Ufwd16[p][ks][l] = { bf16(U[(l&3)*N + 4p + ((l&15)>>2)][32*ks + 8*(l>>4) + j]) }
+//   Ubwd16[kb][rs][l] = { bf16(U[32*rs + 8*(l>>4) + j][16*kb + (l&15)]) }
+// h_t is published twice: fp32 (plain stores, for the time-batched products) and bf16 (sc1, the hand-off).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) |
+           ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+}
+__device__ __forceinline__ u32x4 pack_bf16x8(const float4 &a, const float4 &b) {
+    u32x4 v;
+    v.x = pack_bf16x2(a.x, a.y);
+    v.y = pack_bf16x2(a.z, a.w);
+    v.z = pack_bf16x2(b.x, b.y);
+    v.w = pack_bf16x2(b.z, b.w);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_pack_U_bf16(const float *__restrict__ U, u32x4 *__restrict__ Ufwd16,
+                                                     u32x4 *__restrict__ Ubwd16, int N) {
+    const int G4 = 4 * N;
+    const size_t n16 = (size_t)N * N / 2; // 16-byte fragments per image
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < 2 * n16; e += (size_t)gridDim.x * blockDim.x) {
+        float v[8];
+        if (e < n16) {
+            const int l = (int)(e & 63);
+            const size_t qq = e >> 6;
+            const int ks = (int)(qq % (N / 32)), p = (int)(qq / (N / 32));
+            const int row = (l & 3) * N + 4 * p + ((l & 15) >> 2), k = 32 * ks + 8 * (l >> 4);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = U[(size_t)(k + j) * G4 + row];
+        } else {
+            const size_t e2 = e - n16;
+            const int l = (int)(e2 & 63);
+            const size_t qq = e2 >> 6;
+            const int rs = (int)(qq % (G4 / 32)), kb = (int)(qq / (G4 / 32));
+            const float *src = U + (size_t)(16 * kb + (l & 15)) * G4 + 32 * rs + 8 * (l >> 4);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = src[j];
+        }
+        u32x4 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]);
+        o.w = pack_bf16x2(v[6], v[7]);
+        if (e < n16) Ufwd16[e] = o;
+        else Ubwd16[e - n16] = o;
+    }
+}
+void pack_U_bf16(const float *U, void *Ufwd16, void *Ubwd16, int N, hipStream_t st) {
+    const size_t n = (size_t)N * N;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_pack_U_bf16, dim3(blocks), dim3(256), 0, st, U, reinterpret_cast<u32x4 *>(Ufwd16),
+                       reinterpret_cast<u32x4 *>(Ubwd16), N);
+}
+
+template <int NKS, bool FAST>
+__global__ __launch_bounds__(256) void k_fwd_persistent_bf16(const u32x4 *__restrict__ Ufwd16, const float *__restrict__ W,
+                                                             const float *__restrict__ bias, float *__restrict__ H,
+                                                             unsigned short *Hb, float *__restrict__ C,
+                                                             float *__restrict__ G, const int32_t *__restrict__ xi,
+                                                             unsigned *cnt, unsigned *abortp, unsigned epoch, int S,
+                                                             int B) {
+    constexpr int N = 128 * NKS, G4 = 4 * N;
+    __shared__ float red[4 * 4 * 64];
+    __shared__ int s_abort;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int p = blockIdx.x, g = blockIdx.y, NB = gridDim.x, NG = gridDim.y;
+    const int q = l >> 4, c = l & 15;
+    const int col = 16 * g + c, colc = col < B ? col : B - 1;
+    const int j = 4 * p + q;
+
+    u32x4 a[NKS];
+#pragma unroll
+    for (int i = 0; i < NKS; i++) a[i] = Ufwd16[((size_t)p * (N / 32) + w * NKS + i) * 64 + l];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (w == 0) {
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
+        cprev = C[(size_t)colc * N + j];
+    }
+    const __amdgpu_buffer_rsrc_t rHb = make_rsrc(Hb, (size_t)S * N * B * sizeof(unsigned short));
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+
+    for (int t = 1; t < S; t++) {
+        float wx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w == 0) {
+            const int x = xi[t * B + colc];
+            if (x >= 0) {
+#pragma unroll
+                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
+            }
+            if (t > 1) {
+                const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * 8 * CNT_STRIDE;
+                if (!wait_arrivals(cp, NB, epoch, abortp, l) && l == 0) s_abort = 1;
+            }
+        }
+        __syncthreads();
+        if (s_abort) return;
+
+        u32x4 b[NKS];
+        if (t == 1) { // the carry column exists only in fp32 (written before the launch): round it here
+            const float *hp = H + (size_t)colc * N + 32 * (w * NKS) + 8 * q;
+#pragma unroll
+            for (int i = 0; i < NKS; i++)
+                b[i] = pack_bf16x8(*reinterpret_cast<const float4 *>(hp + 32 * i), *reinterpret_cast<const float4 *>(hp + 32 * i + 4));
+        } else {
+            const int off = (int)((((size_t)(t - 1) * B + colc) * N + 32 * (w * NKS) + 8 * q) * sizeof(unsigned short));
+#pragma unroll
+            for (int i = 0; i < NKS; i++) b[i] = __builtin_amdgcn_raw_buffer_load_b128(rHb, off + 64 * i, 0, 16);
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NKS; i++)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[i]), acc,
+                                                          0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc[r];
+        __syncthreads();
+
+        if (w == 0) {
+            float pre[4];
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) {
+                const float uh = ((red[(0 * 4 + gt) * 64 + l] + red[(1 * 4 + gt) * 64 + l]) + red[(2 * 4 + gt) * 64 + l]) +
+                                 red[(3 * 4 + gt) * 64 + l];
+                pre[gt] = (wx[gt] + uh) + bs[gt]; // R/lstm.cc:176
+            }
+            const float ig = p_sigm<FAST>(pre[0]), og = p_sigm<FAST>(pre[1]), fg = p_sigm<FAST>(pre[2]); // :179
+            const float ug = p_tanh<FAST>(pre[3]);                                                        // :182
+            const float cv = p_tanh<FAST>(ig * ug + fg * cprev);                                          // :185-189
+            const float hv = og * cv;                                                                     // :192
+            cprev = cv;
+            float4 h4;
+            h4.x = __shfl(hv, c, 64);
+            h4.y = __shfl(hv, 16 + c, 64);
+            h4.z = __shfl(hv, 32 + c, 64);
+            h4.w = __shfl(hv, 48 + c, 64);
+            if (q == 0 && col < B) { // the hand-off copy: 4 units as bf16 = one 8-byte sc1 store
+                const unsigned long long pk = (unsigned long long)pack_bf16x2(h4.x, h4.y) |
+                                              ((unsigned long long)pack_bf16x2(h4.z, h4.w) << 32);
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(Hb + ((size_t)t * B + col) * N + 4 * p), pk,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (t + 1 < S) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (l == 0)
+                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * 8 + (p & 7)) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (col < B) {
+                if (q == 0) *reinterpret_cast<float4 *>(H + ((size_t)t * B + col) * N + 4 * p) = h4;
+                float *gc = G + ((size_t)t * B + col) * G4 + j;
+                gc[0] = ig;
+                gc[N] = og;
+                gc[2 * N] = fg;
+                gc[3 * N] = ug;
+                C[((size_t)t * B + col) * N + j] = cv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward recurrence, granule hand-off (LSTM_HIP_GRANULE_HANDOFF; measured slower).  Same decomposition and arithmetic as
 // k_fwd_persistent, but h_t travels as 8-byte {tag, value} granules (Guideline 16, recipe R2: the data
 // IS the flag): the producing lane writes ONE aligned 8-byte sc1 store per value and moves on -- no
@@ -397,15 +567,19 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_g(const float4 *__restri
 // gradient block) in gpart[g]; gemm_fold adds the groups in order afterwards.
 // (Accumulating dU the same way -- 4 x N/16 MFMA accumulator tiles per workgroup -- was built and
 // measured: it needs ~100 more VGPRs, spills, and cost more than the separate GEMM it replaced.)
-template <int NR4W, int COLS, bool FUSE, bool STAMP = false>
+template <int NR4W, int COLS, bool FUSE, bool STAMP = false, bool BF16 = false>
 __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restrict__ Ubwd, float *DG,
                                                            const float *__restrict__ DHy, const float *__restrict__ G,
                                                            const float *__restrict__ C, const float *__restrict__ H,
                                                            const int32_t *__restrict__ xi, float *__restrict__ gpart,
                                                            const float *__restrict__ Why, const float *__restrict__ dY,
                                                            unsigned *cnt, unsigned *abortp, unsigned epoch, int S, int B,
-                                                           int stagger, unsigned long long *stamps = nullptr) {
+                                                           int stagger, unsigned long long *stamps = nullptr,
+                                                           unsigned short *DGb = nullptr) {
     constexpr int N = 32 * NR4W, G4 = 4 * N, nr4 = N / 4;
+    // BF16: Ubwd holds the bf16 image (N/64 16-byte fragments per wave), dg_{t+1} is read from the bf16 copy DGb
+    // (the hand-off), and dg_t is published to DGb (sc1) as well as to DG (fp32, plain, for the dU product)
+    constexpr int NRS = BF16 ? NR4W / 2 : NR4W; // A/B fragments per wave
     constexpr int ETH = 16 * COLS;        // threads with an elementwise / store role
     constexpr int EW = ETH / 64;          // ... i.e. waves 0..EW-1
     extern __shared__ __attribute__((aligned(16))) float dWt[]; // FUSE: [257][64] per-input-byte sums of this WG's rows
@@ -432,10 +606,12 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     // store role (threads 0..ETH-1): float4 of 4 consecutive units for (column sc, gate sg)
     const int sc = (tid >> 4) & (COLS - 1), sg = (tid >> 2) & 3, sq = tid & 3;
 
-    float4 a[NR4W];
+    float4 a[NRS];
 #pragma unroll
-    for (int i = 0; i < NR4W; i++) a[i] = Ubwd[((size_t)kb * nr4 + w * NR4W + i) * 64 + l];
-    const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG, (size_t)S * G4 * B * sizeof(float));
+    for (int i = 0; i < NRS; i++)
+        a[i] = BF16 ? Ubwd[((size_t)kb * (G4 / 32) + w * NRS + i) * 64 + l] : Ubwd[((size_t)kb * nr4 + w * NR4W + i) * 64 + l];
+    const __amdgpu_buffer_rsrc_t rDG = BF16 ? make_rsrc(DGb, (size_t)S * G4 * B * sizeof(unsigned short))
+                                            : make_rsrc(DG, (size_t)S * G4 * B * sizeof(float));
     float dcn = 0.0f; // dcnext, R/lstm.cc:217
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
     if (FUSE)
@@ -596,24 +772,32 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
 
         float dhn = 0.0f;
         if (has_next) {
-            const int off = (int)((((size_t)(t + 1) * B + mcolc) * G4 + 16 * (w * NR4W) + 4 * q) * sizeof(float));
             // Software pipeline with PF fragment loads in flight ahead of the MFMAs.  Left to itself the
             // scheduler keeps only two in flight (a fabric round trip per pair of loads: measured +220
-            // cycles per load), and all NR4W at once measured slower still; sched_barriers pin the order.
-            constexpr int PF = BWD_PF < NR4W ? BWD_PF : NR4W;
+            // cycles per load), and all of them at once measured slower still; sched_barriers pin the order.
+            const int off = BF16 ? (int)((((size_t)(t + 1) * B + mcolc) * G4 + 32 * (w * NRS) + 8 * q) * sizeof(unsigned short))
+                                 : (int)((((size_t)(t + 1) * B + mcolc) * G4 + 16 * (w * NR4W) + 4 * q) * sizeof(float));
+            constexpr int PF = BWD_PF < NRS ? BWD_PF : NRS;
             const bool ld_lane = COLS == 16 || (l & 15) < COLS; // discarded tile columns issue no load
-            float4 b[NR4W];
+            float4 b[NRS];
 #pragma unroll
             for (int i = 0; i < PF; i++)
                 b[i] = (ld_lane && !(STAMP && i >= stagger)) ? ld_sc1(rDG, off + 64 * i) : float4{0.f, 0.f, 0.f, 0.f};
             __builtin_amdgcn_sched_barrier(0);
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < NR4W; i++) {
-                if (i + PF < NR4W)
+            for (int i = 0; i < NRS; i++) {
+                if (i + PF < NRS)
                     b[i + PF] = (ld_lane && !(STAMP && i + PF >= stagger)) ? ld_sc1(rDG, off + 64 * (i + PF))
                                                                            : float4{0.f, 0.f, 0.f, 0.f};
-                if (i & 1) {
+                if (BF16) {
+                    if (i & 1)
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                                       __builtin_bit_cast(bf16x8, b[i]), acc1, 0, 0, 0);
+                    else
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                                       __builtin_bit_cast(bf16x8, b[i]), acc0, 0, 0, 0);
+                } else if (i & 1) {
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc1, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc1, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc1, 0, 0, 0);
@@ -663,7 +847,17 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
             const int scol = COLS * g + sc;
             if (scol < B) {
                 const float4 v = *reinterpret_cast<const float4 *>(stage[cur] + (sc * 4 + sg) * 16 + 4 * sq);
-                st_sc1(v, rDG, (int)((((size_t)t * B + scol) * G4 + sg * N + 16 * kb + 4 * sq) * sizeof(float)));
+                if (BF16) { // fp32 copy for the dU product (read after the launch); bf16 copy is the hand-off
+                    *reinterpret_cast<float4 *>(DG + ((size_t)t * B + scol) * G4 + sg * N + 16 * kb + 4 * sq) = v;
+                    if ((sq & 1) == 0) {
+                        const float4 v2 = *reinterpret_cast<const float4 *>(stage[cur] + (sc * 4 + sg) * 16 + 4 * sq + 4);
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            pack_bf16x8(v, v2), rDG,
+                            (int)((((size_t)t * B + scol) * G4 + sg * N + 16 * kb + 4 * sq) * sizeof(unsigned short)), 0, 16);
+                    }
+                } else {
+                    st_sc1(v, rDG, (int)((((size_t)t * B + scol) * G4 + sg * N + 16 * kb + 4 * sq) * sizeof(float)));
+                }
             }
             if (t > 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the signal
@@ -814,10 +1008,48 @@ int bwd_group_cols(int N, int B, int n_cus) {
 // floats in one column group's partial gradient block [dW | dU | db]
 size_t bwd_partial_floats(int N) { return (size_t)4 * N * 256 + (size_t)4 * N * N + (size_t)4 * N + (size_t)256 * N; }
 
+void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, float *H, unsigned short *Hb, float *C,
+                         float *G, const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
+                         bool fast, hipStream_t st) {
+    const dim3 grid(N / 4, (B + 15) / 16), block(256);
+    const u32x4 *U16 = reinterpret_cast<const u32x4 *>(Ufwd16);
+    switch (N / 128) {
+#define X(k)                                                                                                             \
+    case k:                                                                                                              \
+        if (fast) hipLaunchKernelGGL((k_fwd_persistent_bf16<k, true>), grid, block, 0, st, U16, W, bias, H, Hb, C, G, xi, cnt, abortp, epoch, S, B); \
+        else hipLaunchKernelGGL((k_fwd_persistent_bf16<k, false>), grid, block, 0, st, U16, W, bias, H, Hb, C, G, xi, cnt, abortp, epoch, S, B);    \
+        break;
+        X(1) X(2) X(4) X(8)
+#undef X
+    }
+}
+
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,
                     const int32_t *xi, float *gpart, const float *Why, const float *dY, unsigned *cnt, unsigned *abortp,
-                    unsigned epoch, int N, int S, int B, int cols, hipStream_t st, unsigned long long *stamps) {
+                    unsigned epoch, int N, int S, int B, int cols, hipStream_t st, unsigned long long *stamps,
+                    unsigned short *DGb) {
     const dim3 grid(N / 16, (B + cols - 1) / cols), block(512);
+    if (DGb != nullptr) { // bf16 recurrence: 8-column groups; fused when gpart is given
+        const bool fuse16 = gpart != nullptr;
+        const size_t lds16 = fuse16 ? 257 * 64 * sizeof(float) : 0;
+        switch (N / 32) {
+#define X(k)                                                                                                              \
+    case k:                                                                                                               \
+        if (fuse16) {                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persistent<k, 8, true, false, true>),       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 257 * 64 * sizeof(float));             \
+            hipLaunchKernelGGL((k_bwd_persistent<k, 8, true, false, true>), grid, block, lds16, st, Ubwd, DG, DHy, G, C, H, xi, \
+                               gpart, Why, dY, cnt, abortp, epoch, S, B, 0, nullptr, DGb);                                \
+        } else {                                                                                                          \
+            hipLaunchKernelGGL((k_bwd_persistent<k, 8, false, false, true>), grid, block, 0, st, Ubwd, DG, DHy, G, C, H, xi, \
+                               gpart, Why, dY, cnt, abortp, epoch, S, B, 0, nullptr, DGb);                                \
+        }                                                                                                                 \
+        break;
+            X(4) X(8) X(16) X(32)
+#undef X
+        }
+        return;
+    }
     static const int stagger = getenv("LSTM_HIP_BWD_STAGGER") ? atoi(getenv("LSTM_HIP_BWD_STAGGER")) : 0;
     const bool fuse = gpart != nullptr;
     const size_t lds = fuse ? 257 * 64 * sizeof(float) : 0;

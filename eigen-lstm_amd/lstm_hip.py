@@ -24,6 +24,7 @@ GRANULE_HANDOFF = 8
 DEBUG_STAMPS = 16
 NO_OVERLAP = 32
 NO_FUSED_GRADS = 64
+BF16_RECURRENCE = 128
 UNIQUE_ID_BYTES = 128
 VOCAB = 256
 

@@ -50,6 +50,9 @@ extern "C" {
 #define LSTM_HIP_GRANULE_HANDOFF 8u /* forward hand-off by 8-byte {value, tag} granules instead of the default sc1
                                       payload + sharded counters (measured 1.6-1.9x slower; kept for A/B runs) */
 
+#define LSTM_HIP_BF16_RECURRENCE 128u /* bf16 MFMA in the two recurrent products (U and the h / dg hand-off rounded to
+                                      bfloat16, fp32 accumulate, fp32 master weights and everything else);
+                                      needs N % 128 == 0 */
 #define LSTM_HIP_NO_FUSED_GRADS 64u  /* compute dU/dW/db after the backward recurrence (GEMM + sorted segment sums)
                                       instead of accumulating them inside it */
 #define LSTM_HIP_NO_OVERLAP 32u      /* run the time-batched products after the recurrences instead of beside them */

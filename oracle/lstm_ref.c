@@ -55,6 +55,22 @@
 
 #define EPS 1e-10 /* R/lstm.cc:25 -- double literal */
 
+/* bf16 recurrence mode (BASELINE configs[4], "bf16 MFMA path"): the operands of the two recurrent products
+ * U*h_prev (R/lstm.cc:176) and U^T*dg (R/lstm.cc:255) are rounded to bfloat16 (round-to-nearest-even, what
+ * v_cvt_pk_bf16_f32 does); products are then exact in fp32 and the accumulation stays fp32.  Everything else
+ * (W gather, biases, gates, output layer, every weight gradient, Adagrad on fp32 master weights) is unchanged. */
+static int g_bf16_recurrence = 0;
+void ref_set_bf16_recurrence(int on) { g_bf16_recurrence = on; }
+static inline float bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return x; /* NaN stays NaN */
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
 /* ------------------------------------------------------------------------------------------
  * RNG.  The reference seeds a fresh mt19937 from std::random_device on every randn() call
  * (R/lstm.cc:370-372), so it has no reproducible stream to match.  The build defines one:
@@ -191,6 +207,12 @@ void FN(ref_forward)(int N, int M, int S, int B, const REAL *P, const int32_t *x
     double lb = 0.0, ln_ = 0.0;
     REAL *surpr = (REAL *)malloc(sizeof(REAL) * B);
     double *surpn = (double *)malloc(sizeof(double) * B);
+    REAL *Ub = NULL; /* bf16 mode: U rounded once */
+    if (g_bf16_recurrence) {
+        Ub = (REAL *)malloc(sizeof(REAL) * (size_t)G * N);
+        for (size_t i = 0; i < (size_t)G * N; i++) Ub[i] = (REAL)bf16_rne((float)p.U[i]);
+    }
+    const REAL *Urec = Ub ? Ub : p.U;
     for (int t = 1; t < S; t++) {
         REAL *gt = g + (size_t)t * G * B, *ht = h + (size_t)t * N * B, *ct = c + (size_t)t * N * B;
         const REAL *hp = h + (size_t)(t - 1) * N * B, *cp = c + (size_t)(t - 1) * N * B;
@@ -207,8 +229,8 @@ void FN(ref_forward)(int N, int M, int S, int B, const REAL *P, const int32_t *x
             int xk = xi[t * B + b];
             for (int r = 0; r < G; r++) gc[r] = 0;
             for (int k = 0; k < N; k++) {
-                const REAL hk = hp[(size_t)b * N + k];
-                const REAL *Uk = p.U + (size_t)k * G;
+                const REAL hk = Ub ? (REAL)bf16_rne((float)hp[(size_t)b * N + k]) : hp[(size_t)b * N + k];
+                const REAL *Uk = Urec + (size_t)k * G;
                 for (int r = 0; r < G; r++) gc[r] += Uk[r] * hk;
             }
             for (int r = 0; r < G; r++) {
@@ -250,7 +272,7 @@ void FN(ref_forward)(int N, int M, int S, int B, const REAL *P, const int32_t *x
         }
         lb += (double)(surpr_sum / (REAL)B); /* opt:249 */
     }
-    free(surpr); free(surpn);
+    free(surpr); free(surpn); free(Ub);
     if (loss_bits) *loss_bits = lb;
     if (loss_nats) *loss_nats = ln_;
 }
@@ -270,6 +292,13 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
     REAL *dhnext = (REAL *)calloc((size_t)N * B, sizeof(REAL));
     REAL *dcnext = (REAL *)calloc((size_t)N * B, sizeof(REAL));
     REAL *utmp = (REAL *)malloc(sizeof(REAL) * (size_t)N * G);
+    REAL *Ub = NULL, *dgb = NULL; /* bf16 mode: rounded operands of U^T*dg */
+    if (g_bf16_recurrence) {
+        Ub = (REAL *)malloc(sizeof(REAL) * (size_t)G * N);
+        dgb = (REAL *)malloc(sizeof(REAL) * (size_t)G * B);
+        for (size_t i = 0; i < (size_t)G * N; i++) Ub[i] = (REAL)bf16_rne((float)p.U[i]);
+    }
+    const REAL *Urec = Ub ? Ub : p.U;
     for (int t = S - 1; t > 0; t--) {
         const REAL *gt = g + (size_t)t * G * B, *ht = h + (size_t)t * N * B, *ct = c + (size_t)t * N * B;
         const REAL *hp = h + (size_t)(t - 1) * N * B, *cp = c + (size_t)(t - 1) * N * B;
@@ -342,18 +371,21 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
             d.b[r] += acc;
         }
         /* dhnext = U^T * dg ; dcnext = dc .* f   (opt:302-303) */
+        if (dgb)
+            for (size_t i = 0; i < (size_t)G * B; i++) dgb[i] = (REAL)bf16_rne((float)dg[i]);
+        const REAL *dgrec = dgb ? dgb : dg;
 #pragma omp parallel for schedule(static)
         for (int b = 0; b < B; b++)
             for (int k = 0; k < N; k++) {
                 REAL acc = 0;
-                for (int r = 0; r < G; r++) acc += p.U[(size_t)k * G + r] * dg[(size_t)b * G + r];
+                for (int r = 0; r < G; r++) acc += Urec[(size_t)k * G + r] * dgrec[(size_t)b * G + r];
                 dhnext[(size_t)b * N + k] = acc;
             }
         for (int b = 0; b < B; b++)
             for (int j = 0; j < N; j++)
                 dcnext[(size_t)b * N + j] = dc[(size_t)b * N + j] * gt[(size_t)b * G + 2 * N + j];
     }
-    free(dy); free(dh); free(dc); free(dg); free(dhnext); free(dcnext); free(utmp);
+    free(dy); free(dh); free(dc); free(dg); free(dhnext); free(dcnext); free(utmp); free(Ub); free(dgb);
 }
 
 /* m += d.*d ; p -= lr * d ./ sqrt(m + eps)   R/lstm.cc:261-272, over the whole flat block */

@@ -54,6 +54,10 @@ class Oracle:
     def _p(self, a):
         return a.ctypes.data_as(C.POINTER(self.c_t))
 
+    def set_bf16_recurrence(self, on):
+        """bf16 operands (RNE) in the two recurrent products, fp32 accumulate (BASELINE configs[4] semantics)."""
+        self.lib.ref_set_bf16_recurrence(1 if on else 0)
+
     # ---- RNG -------------------------------------------------------------------------------
     def rng(self, seed):
         buf = C.create_string_buffer(self.lib.ref_rng_sizeof())

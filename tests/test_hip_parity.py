@@ -424,3 +424,37 @@ def test_create_destroy_does_not_leak():
     L.forward()
     L.synchronize()
     L.close()
+
+
+@pytest.mark.parametrize("N,S,B", [(128, 6, 8), (256, 10, 24), (512, 12, 64), (1024, 4, 16)])
+def test_bf16_recurrence_matches_bf16_oracle(N, S, B, oracle32):
+    """LSTM_HIP_BF16_RECURRENCE (BASELINE configs[4] semantics: bf16 MFMA in the recurrent products, fp32
+    accumulate and fp32 everything else) against the oracle in the same mode (operands rounded to bfloat16,
+    round-to-nearest-even).  Both sides round the same values, so the only extra divergence over the fp32 case
+    is an operand landing on the other side of a bf16 rounding boundary (1 bf16 ulp = 2^-8 relative, on one of N
+    terms).  Tolerances: activations 2e-3 of scale, loss 1e-3*(S-1) bits, gradients 1e-2 of scale per tensor
+    (SURVEY 8d proposes 2e-2 for bf16 inputs)."""
+    import lstm_hip
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=N + B, scale=0.05, empty=((1, 0),))
+    oracle32.set_bf16_recurrence(True)
+    try:
+        fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
+        dref = oracle32.backward(N, 256, S, B, P, xi, ti, fw)
+    finally:
+        oracle32.set_bf16_recurrence(False)
+    fw32 = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
+    got = _run_hip(lstm_hip, N, S, B, P, xi, ti, h0, c0, flags=lstm_hip.BF16_RECURRENCE)
+    for t in range(1, S):
+        for name in ("h", "c", "g"):
+            assert gu.max_rel(got[name][t - 1], fw[name][t]) <= 2e-3, (name, t)
+    assert abs(got["loss"] - fw["loss_bits"]) <= 1e-3 * (S - 1)
+    rep = gu.grads_report(got["grads"], dref, N)
+    assert max(rep.values()) <= 1e-2, rep
+    # and it really is the bf16 model: closer to the bf16 oracle than the fp32 oracle is
+    assert gu.max_rel(got["h"][-1], fw["h"][S - 1]) < 0.5 * gu.max_rel(fw32["h"][S - 1], fw["h"][S - 1]) + 1e-6
+
+
+def test_bf16_flag_is_refused_where_unsupported():
+    import lstm_hip
+    with pytest.raises(lstm_hip.LstmHipError):
+        lstm_hip.Lstm(64, 5, 8, flags=lstm_hip.BF16_RECURRENCE)   # N not a multiple of 128
