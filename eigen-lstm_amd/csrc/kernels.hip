@@ -599,62 +599,68 @@ void softmax_loss_dy(float *Y, float *P, const float *by, const int32_t *ti, flo
 
 // dby = rowsum(dY) (R/lstm.cc:227): fold the per-wave partials.  1024 threads = 64 float4 row groups
 // x 16 phases; phase q sums partials q, q+16, ... in order, then the 16 phase sums are added in order.
-__device__ __forceinline__ void dby_finish_body(const float *__restrict__ part, int n_parts, float *__restrict__ dby,
-                                                float4 (*red)[64]) {
-    const int m4 = threadIdx.x & 63, q = threadIdx.x >> 6;
-    float4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int p = q; p < n_parts; p += 16) {
-        const float4 v = reinterpret_cast<const float4 *>(part + (size_t)p * 256)[m4];
-        s.x += v.x;
-        s.y += v.y;
-        s.z += v.z;
-        s.w += v.w;
-    }
-    red[q][m4] = s;
-    __syncthreads();
-    if (q == 0) {
-        float4 t = red[0][m4];
-        for (int i = 1; i < 16; i++) {
-            t.x += red[i][m4].x;
-            t.y += red[i][m4].y;
-            t.z += red[i][m4].z;
-            t.w += red[i][m4].w;
-        }
-        reinterpret_cast<float4 *>(dby)[m4] = t;
-    }
-}
-
 // loss += surprisals.sum() / B per step (OV/lstm_eigen_opt/lstm.cc:249): float sum over the columns
 // of a step, divided by the (global) batch, accumulated over steps in double.
-// block 0: window loss; block 1 (when dby != null): dby = rowsum(dY) from the per-wave partials
+// block 0: window loss; blocks 1..4 (when dby != null): dby = rowsum(dY) from the per-wave partials, 64 rows each
 __global__ __launch_bounds__(1024) void k_loss_dby(const float *__restrict__ colloss, int steps, int B, int Bg,
                                                    double *__restrict__ out, const float *__restrict__ dby_part,
                                                    int n_parts, float *__restrict__ dby) {
     __shared__ float4 red[16][64];
-    if (blockIdx.x == 1) {
-        dby_finish_body(dby_part, n_parts, dby, red);
+    if (blockIdx.x >= 1) { // 16 float4 row groups x 64 phases; phases folded in order
+        const int m4 = (blockIdx.x - 1) * 16 + (threadIdx.x & 15), ph = threadIdx.x >> 4;
+        float4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int p = ph; p < n_parts; p += 64) {
+            const float4 v = reinterpret_cast<const float4 *>(dby_part + (size_t)p * 256)[m4];
+            s.x += v.x;
+            s.y += v.y;
+            s.z += v.z;
+            s.w += v.w;
+        }
+        float4 *r = &red[0][0];
+        r[ph * 16 + (threadIdx.x & 15)] = s;
+        __syncthreads();
+        if (ph == 0) {
+            float4 t = r[threadIdx.x & 15];
+            for (int i = 1; i < 64; i++) {
+                const float4 v = r[i * 16 + (threadIdx.x & 15)];
+                t.x += v.x;
+                t.y += v.y;
+                t.z += v.z;
+                t.w += v.w;
+            }
+            reinterpret_cast<float4 *>(dby)[m4] = t;
+        }
         return;
     }
+    // loss: one thread per timestep walks its B columns in order (the reference's float sum over a step's
+    // columns, OV/lstm_eigen_opt/lstm.cc:249) with 8 loads in flight; steps are then added in order in double
     double *part = reinterpret_cast<double *>(&red[0][0]);
     double acc = 0.0;
     for (int t = threadIdx.x; t < steps; t += blockDim.x) {
+        const float *cl = colloss + (size_t)t * B;
         float s = 0.0f;
-#pragma unroll 8
-        for (int b = 0; b < B; b++) s += colloss[(size_t)t * B + b];
+        int b = 0;
+        for (; b + 8 <= B; b += 8) {
+            const float v0 = cl[b], v1 = cl[b + 1], v2 = cl[b + 2], v3 = cl[b + 3], v4 = cl[b + 4], v5 = cl[b + 5],
+                        v6 = cl[b + 6], v7 = cl[b + 7];
+            s = (((((((s + v0) + v1) + v2) + v3) + v4) + v5) + v6) + v7;
+        }
+        for (; b < B; b++) s += cl[b];
         acc += (double)(s / (float)Bg);
     }
     part[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         double tot = 0.0;
-        for (int i = 0; i < (int)blockDim.x; i++) tot += part[i];
+        const int n = steps < (int)blockDim.x ? steps : (int)blockDim.x;
+        for (int i = 0; i < n; i++) tot += part[i];
         out[0] = tot;
     }
 }
 void loss_reduce(const float *colloss, int steps, int B, int B_global, double *out, const float *dby_part, int n_parts,
                  float *dby, hipStream_t st) {
-    hipLaunchKernelGGL(k_loss_dby, dim3(dby ? 2 : 1), dim3(1024), 0, st, colloss, steps, B, B_global, out, dby_part,
+    hipLaunchKernelGGL(k_loss_dby, dim3(dby ? 5 : 1), dim3(1024), 0, st, colloss, steps, B, B_global, out, dby_part,
                        n_parts, dby);
 }
 
