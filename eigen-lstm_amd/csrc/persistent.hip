@@ -51,7 +51,20 @@ template <bool FAST> __device__ __forceinline__ float p_tanh(float x) {
 #define FWD_PF 4
 #endif
 
-constexpr int CNT_STRIDE = 16;       // uints between shards: one 64-byte line each
+#ifndef CNT_STRIDE_U
+#define CNT_STRIDE_U 16
+#endif
+constexpr int CNT_STRIDE = CNT_STRIDE_U; // uints between shards: one 64-byte line each
+// Counter shards per (step, group): a power of two <= 64 (one poll instruction reads them all).  Arrivals and polls
+// contend on the counter lines: with 128 producers per group (forward, N=512) 64 shards measured 388 us against 419
+// with 8 (and 497 with one); the backward recurrence has 32 producers per group and is flat from 8 up.
+#ifndef FWD_SH
+#define FWD_SH 64
+#endif
+#ifndef BWD_SH
+#define BWD_SH 8
+#endif
+constexpr int CNT_SLOTS = 64;
 constexpr int SPIN_LIMIT = 1 << 21;  // bounded spin; ~seconds
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, size_t bytes) {
@@ -79,13 +92,14 @@ __device__ __forceinline__ void st_sc1(float4 f, __amdgpu_buffer_rsrc_t r, int b
 // wave-level wait until all `n_prod` producers (sharded by id & 7) have arrived at `cp`.
 // Returns false on time-out / abort.  Called by one whole wave.
 // Counters are never reset: launch number `epoch` (1, 2, ...) waits for epoch * (arrivals per launch).
+template <int CNT_SH>
 __device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, unsigned epoch, unsigned *abortp, int lane,
                                               int first_delay = 0) {
-    const unsigned expect = lane < 8 ? epoch * (unsigned)((n_prod - lane + 7) / 8) : 0u;
+    const unsigned expect = lane < CNT_SH ? epoch * (unsigned)((n_prod - lane + CNT_SH - 1) / CNT_SH) : 0u;
     for (int i = 0; i < first_delay; i++) __builtin_amdgcn_s_sleep(1); // 64 cycles each
     for (int spins = 0;; spins++) {
         unsigned v = 0;
-        if (lane < 8) v = __hip_atomic_load(cp + lane * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < CNT_SH) v = __hip_atomic_load(cp + lane * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__all(v >= expect)) return true;
         if (spins > SPIN_LIMIT) break;
         if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
@@ -103,6 +117,9 @@ __device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, un
 #define STAMP_AT(k)                                                                      \
     if (STAMP && l == 0 && w == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
         stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#ifndef FWD_WAVE_POLL
+#define FWD_WAVE_POLL 0
+#endif
 template <int NK4W, bool FAST, bool STAMP = false>
 __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict__ Ufwd, const float *__restrict__ W,
                                                         const float *__restrict__ bias, float *H, float *__restrict__ C,
@@ -145,13 +162,25 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
 #pragma unroll
                 for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
             }
+#if !FWD_WAVE_POLL
             if (t > 1) {
-                const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * 8 * CNT_STRIDE;
-                if (!wait_arrivals(cp, NB, epoch, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
+                const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
+                if (!wait_arrivals<FWD_SH>(cp, NB, epoch, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
             }
+#endif
         }
+#if FWD_WAVE_POLL
+        // every wave polls for itself and goes straight to its loads: no workgroup barrier on the chain.  The red[]
+        // buffer needs none either -- no wave passes this poll before wave 0 of its own workgroup has published h_{t-1},
+        // which it does after reading red[].  A time-out is carried to the barrier below so the exit stays uniform.
+        if (t > 1) {
+            const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
+            if (!wait_arrivals<FWD_SH>(cp, NB, epoch, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
+        }
+#else
         __syncthreads();
         if (s_abort) return;
+#endif
         STAMP_AT(1)
 
         const int off = (int)((((size_t)(t - 1) * B + colc) * N + 16 * (w * NK4W) + 4 * q) * sizeof(float));
@@ -183,6 +212,9 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
 #pragma unroll
         for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
         __syncthreads();
+#if FWD_WAVE_POLL
+        if (s_abort) return;
+#endif
         STAMP_AT(2)
 
         if (w == 0) {
@@ -210,7 +242,7 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 STAMP_AT(4)
                 if (l == 0)
-                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * 8 + (p & 7)) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * CNT_SLOTS + (p & (FWD_SH - 1))) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
             }
             if (col < B) {
@@ -325,8 +357,8 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_bf16(const u32x4 *__rest
                 for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
             }
             if (t > 1) {
-                const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * 8 * CNT_STRIDE;
-                if (!wait_arrivals(cp, NB, epoch, abortp, l) && l == 0) s_abort = 1;
+                const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
+                if (!wait_arrivals<FWD_SH>(cp, NB, epoch, abortp, l) && l == 0) s_abort = 1;
             }
         }
         __syncthreads();
@@ -379,7 +411,7 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_bf16(const u32x4 *__rest
             if (t + 1 < S) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (l == 0)
-                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * 8 + (p & 7)) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * CNT_SLOTS + (p & (FWD_SH - 1))) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
             }
             if (col < B) {
@@ -763,8 +795,8 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
         }
         if (FUSE && w >= 4 && t >= 2) output_layer_fetch(t - 1);
         if (has_next && w == 0) {
-            const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * 8 * CNT_STRIDE;
-            if (!wait_arrivals(cpn, NBK, epoch, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
+            const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
+            if (!wait_arrivals<BWD_SH>(cpn, NBK, epoch, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
         }
         __syncthreads();
         if (s_abort) return;
@@ -864,7 +896,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                 pair_sync();
                 BSTAMP_AT(4)
                 if (tid == 0)
-                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * 8 + (kb & 7)) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * CNT_SLOTS + (kb & (BWD_SH - 1))) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
             }
         } else if (FUSE) {
@@ -918,7 +950,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
 __global__ __launch_bounds__(64) void k_wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch,
                                                       unsigned *abortp) {
     for (int g = 0; g < NG; g++)
-        if (!wait_arrivals(cnt + (size_t)(t * NG + g) * 8 * CNT_STRIDE, n_prod, epoch, abortp, threadIdx.x)) return;
+        if (!wait_arrivals<FWD_SH>(cnt + (size_t)(t * NG + g) * CNT_SLOTS * CNT_STRIDE, n_prod, epoch, abortp, threadIdx.x)) return;
 }
 void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, unsigned *abortp, hipStream_t st) {
     hipLaunchKernelGGL(k_wait_progress, dim3(1), dim3(64), 0, st, cnt, t, NG, n_prod, epoch, abortp);
@@ -929,7 +961,7 @@ void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, uns
 // ------------------------------------------------------------------------------------------------
 size_t persistent_counter_bytes(int S, int B) {
     const int NG = (B + 7) / 8; // the backward recurrence may use 8-column groups
-    return (size_t)(S + 1) * NG * 8 * CNT_STRIDE * sizeof(unsigned);
+    return (size_t)(S + 1) * NG * CNT_SLOTS * CNT_STRIDE * sizeof(unsigned);
 }
 
 template <class K> static int blocks_per_cu(K kernel, int threads) {
