@@ -58,6 +58,14 @@ constexpr int CNT_STRIDE = CNT_STRIDE_U; // uints between shards: one 64-byte li
 // Counter shards per (step, group): a power of two <= 64 (one poll instruction reads them all).  Arrivals and polls
 // contend on the counter lines: with 128 producers per group (forward, N=512) 64 shards measured 388 us against 419
 // with 8 (and 497 with one); the backward recurrence has 32 producers per group and is flat from 8 up.
+// Also measured: one flag word per producer instead of a counter (dense 494 us, one line each 440 us) and every wave
+// polling for itself instead of poll -> barrier (1275 us): the polls themselves load the counter lines.
+// Workgroup -> (tile, column group): blocks are dealt round-robin over the 8 XCDs in dispatch order (observed, not
+// promised: speed only).  GROUP_REMAP=1 makes blocks b and b+NG members of one group, so a group's hand-off lines
+// are fetched into one or two XCD L2s instead of all eight (backward 504 -> 492 us, forward unchanged).
+#ifndef GROUP_REMAP
+#define GROUP_REMAP 1
+#endif
 #ifndef FWD_SH
 #define FWD_SH 64
 #endif
@@ -92,6 +100,9 @@ __device__ __forceinline__ void st_sc1(float4 f, __amdgpu_buffer_rsrc_t r, int b
 // wave-level wait until all `n_prod` producers (sharded by id & 7) have arrived at `cp`.
 // Returns false on time-out / abort.  Called by one whole wave.
 // Counters are never reset: launch number `epoch` (1, 2, ...) waits for epoch * (arrivals per launch).
+#ifndef POLL_SLEEP
+#define POLL_SLEEP 1
+#endif
 template <int CNT_SH>
 __device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, unsigned epoch, unsigned *abortp, int lane,
                                               int first_delay = 0) {
@@ -103,7 +114,7 @@ __device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, un
         if (__all(v >= expect)) return true;
         if (spins > SPIN_LIMIT) break;
         if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(POLL_SLEEP);
     }
     if (lane == 0) __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return false;
@@ -117,9 +128,6 @@ __device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, un
 #define STAMP_AT(k)                                                                      \
     if (STAMP && l == 0 && w == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
         stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 8 + (k)] = __builtin_amdgcn_s_memtime();
-#ifndef FWD_WAVE_POLL
-#define FWD_WAVE_POLL 0
-#endif
 template <int NK4W, bool FAST, bool STAMP = false>
 __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict__ Ufwd, const float *__restrict__ W,
                                                         const float *__restrict__ bias, float *H, float *__restrict__ C,
@@ -130,7 +138,9 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
     __shared__ float red[4 * 4 * 64];
     __shared__ int s_abort;
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int p = blockIdx.x, g = blockIdx.y, NB = gridDim.x, NG = gridDim.y;
+    const int NB = gridDim.x, NG = gridDim.y;
+    const int lin_ = blockIdx.x + NB * blockIdx.y;
+    const int p = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
     const int q = l >> 4, c = l & 15;
     const int col = 16 * g + c, colc = col < B ? col : B - 1;
     const int j = 4 * p + q;
@@ -162,25 +172,13 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
 #pragma unroll
                 for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
             }
-#if !FWD_WAVE_POLL
             if (t > 1) {
                 const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
                 if (!wait_arrivals<FWD_SH>(cp, NB, epoch, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
             }
-#endif
         }
-#if FWD_WAVE_POLL
-        // every wave polls for itself and goes straight to its loads: no workgroup barrier on the chain.  The red[]
-        // buffer needs none either -- no wave passes this poll before wave 0 of its own workgroup has published h_{t-1},
-        // which it does after reading red[].  A time-out is carried to the barrier below so the exit stays uniform.
-        if (t > 1) {
-            const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
-            if (!wait_arrivals<FWD_SH>(cp, NB, epoch, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
-        }
-#else
         __syncthreads();
         if (s_abort) return;
-#endif
         STAMP_AT(1)
 
         const int off = (int)((((size_t)(t - 1) * B + colc) * N + 16 * (w * NK4W) + 4 * q) * sizeof(float));
@@ -212,9 +210,6 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
 #pragma unroll
         for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
         __syncthreads();
-#if FWD_WAVE_POLL
-        if (s_abort) return;
-#endif
         STAMP_AT(2)
 
         if (w == 0) {
@@ -330,7 +325,9 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_bf16(const u32x4 *__rest
     __shared__ float red[4 * 4 * 64];
     __shared__ int s_abort;
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int p = blockIdx.x, g = blockIdx.y, NB = gridDim.x, NG = gridDim.y;
+    const int NB = gridDim.x, NG = gridDim.y;
+    const int lin_ = blockIdx.x + NB * blockIdx.y;
+    const int p = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
     const int q = l >> 4, c = l & 15;
     const int col = 16 * g + c, colc = col < B ? col : B - 1;
     const int j = 4 * p + q;
@@ -625,7 +622,9 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     __shared__ float dhyb[2][16 * 16];
     __shared__ unsigned s_ol;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int kb = blockIdx.x, g = blockIdx.y, NBK = gridDim.x, NG = gridDim.y;
+    const int NBK = gridDim.x, NG = gridDim.y;
+    const int lin_ = blockIdx.x + NBK * blockIdx.y;
+    const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
     const int q = l >> 4;
     // COLS = 16: the MFMA tile is full.  COLS = 8: lanes 8..15 of the B operand are never used (their tile
     // columns are discarded) -- the matrix pipe is not what bounds a step, and 8-column groups put
