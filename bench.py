@@ -26,6 +26,9 @@ import time
 
 import numpy as np
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails otherwise); set before HIP loads
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "eigen-lstm_amd"))
 if os.environ.get("LSTM_BENCH_FAKE_GPU") == "1":  # CPU test of the multi-rank plumbing only (tests/fake_gpu)

@@ -345,6 +345,7 @@ int main(int argc, char **argv) {
     for (int r = 0; r < o.gpus; r++) {
         int up[2], down[2];
         if (pipe(up) != 0 || pipe(down) != 0) die("pipe");
+        setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); // RCCL across processes needs dmabuf IPC on this driver
         pid_t pid = fork();
         if (pid < 0) die("fork");
         if (pid == 0) {
