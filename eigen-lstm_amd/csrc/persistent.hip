@@ -253,6 +253,129 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward recurrence, second form: grid (N/8, ceil(B/16)), 512 threads, one workgroup per CU at the headline shape.
+// A workgroup owns 8 units (two of the row tiles above, same packed image) and all of K over 8 waves, so every
+// fragment of h_{t-1} a lane loads feeds two MFMA tiles: half the load instructions per lane and half the bytes per
+// CU of the first form (a timing probe with half the loads removed from the first form: 387 -> 350 us).  Waves 0
+// and 1 each finish one row tile (gates, cell, publish, arrive): to the counters they are the producers 2p and
+// 2p+1 of the first form, so the counter protocol, k_wait_progress and the backward kernel see no difference.
+// N = 128*NKW.
+// ------------------------------------------------------------------------------------------------
+template <int NKW, bool FAST>
+__global__ __launch_bounds__(512) void k_fwd_persistent2(const float4 *__restrict__ Ufwd, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, float *H, float *__restrict__ C,
+                                                         float *__restrict__ G, const int32_t *__restrict__ xi,
+                                                         unsigned *cnt, unsigned *abortp, unsigned epoch, int S, int B) {
+    constexpr int N = 128 * NKW, G4 = 4 * N, nk4 = N / 16;
+    __shared__ float red[8 * 2 * 4 * 64];
+    __shared__ int s_abort;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int NB2 = gridDim.x, NG = gridDim.y;
+    const int lin_ = blockIdx.x + NB2 * blockIdx.y;
+    const int p2 = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
+    const int q = l >> 4, c = l & 15;
+    const int col = 16 * g + c, colc = col < B ? col : B - 1;
+    const int p = 2 * p2 + (w & 1); // the row tile a gating wave (w < 2) finishes
+    const int j = 4 * p + q;
+
+    float4 a0[NKW], a1[NKW];
+#pragma unroll
+    for (int i = 0; i < NKW; i++) {
+        a0[i] = Ufwd[((size_t)(2 * p2) * nk4 + w * NKW + i) * 64 + l];
+        a1[i] = Ufwd[((size_t)(2 * p2 + 1) * nk4 + w * NKW + i) * 64 + l];
+    }
+    float bs[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (w < 2) {
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
+        cprev = C[(size_t)colc * N + j];
+    }
+    const __amdgpu_buffer_rsrc_t rH = make_rsrc(H, (size_t)S * N * B * sizeof(float));
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+
+    for (int t = 1; t < S; t++) {
+        float wx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w < 2) {
+            const int x = xi[t * B + colc];
+            if (x >= 0) {
+#pragma unroll
+                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
+            }
+        }
+        if (w == 0 && t > 1) {
+            const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
+            if (!wait_arrivals<FWD_SH>(cp, 2 * NB2, epoch, abortp, l) && l == 0) s_abort = 1;
+        }
+        __syncthreads();
+        if (s_abort) return;
+
+        const int off = (int)((((size_t)(t - 1) * B + colc) * N + 16 * (w * NKW) + 4 * q) * sizeof(float));
+        constexpr int PF = FWD_PF < NKW ? FWD_PF : NKW;
+        float4 b[NKW];
+#pragma unroll
+        for (int i = 0; i < PF; i++) b[i] = ld_sc1(rH, off + 64 * i);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NKW; i++) {
+            if (i + PF < NKW) b[i + PF] = ld_sc1(rH, off + 64 * (i + PF));
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].x, b[i].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].x, b[i].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].y, b[i].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].y, b[i].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].z, b[i].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].z, b[i].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].w, b[i].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].w, b[i].w, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            red[((w * 2 + 0) * 4 + r) * 64 + l] = acc0[r];
+            red[((w * 2 + 1) * 4 + r) * 64 + l] = acc1[r];
+        }
+        __syncthreads();
+
+        if (w < 2) {
+            float pre[4];
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) {
+                float uh = red[((0 * 2 + w) * 4 + gt) * 64 + l];
+#pragma unroll
+                for (int ww = 1; ww < 8; ww++) uh += red[((ww * 2 + w) * 4 + gt) * 64 + l];
+                pre[gt] = (wx[gt] + uh) + bs[gt]; // R/lstm.cc:176
+            }
+            const float ig = p_sigm<FAST>(pre[0]), og = p_sigm<FAST>(pre[1]), fg = p_sigm<FAST>(pre[2]); // :179
+            const float ug = p_tanh<FAST>(pre[3]);                                                        // :182
+            const float cv = p_tanh<FAST>(ig * ug + fg * cprev);                                          // :185-189
+            const float hv = og * cv;                                                                     // :192
+            cprev = cv;
+            float4 h4;
+            h4.x = __shfl(hv, c, 64);
+            h4.y = __shfl(hv, 16 + c, 64);
+            h4.z = __shfl(hv, 32 + c, 64);
+            h4.w = __shfl(hv, 48 + c, 64);
+            if (q == 0 && col < B) st_sc1(h4, rH, (int)((((size_t)t * B + col) * N + 4 * p) * sizeof(float)));
+            if (t + 1 < S) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (l == 0)
+                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * CNT_SLOTS + (p & (FWD_SH - 1))) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (col < B) {
+                float *gc = G + ((size_t)t * B + col) * G4 + j;
+                gc[0] = ig;
+                gc[N] = og;
+                gc[2 * N] = fg;
+                gc[3 * N] = ug;
+                C[((size_t)t * B + col) * N + j] = cv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 recurrence (LSTM_HIP_BF16_RECURRENCE, BASELINE configs[4]): the operands of U*h_prev are bfloat16
 // (round-to-nearest-even of the fp32 master weights and of the published h), the accumulation is fp32,
 // everything else is the fp32 kernel above.  MFMA 16x16x32 bf16: A[row=l&15][k=8*(l>>4)+j],
@@ -972,10 +1095,24 @@ template <class K> static int blocks_per_cu(K kernel, int threads) {
 #define FWD_CASES(X) X(1) X(2) X(4) X(8) X(16)
 #define BWD_CASES(X) X(2) X(4) X(8) X(16) X(32)
 
+// second form of the forward recurrence (k_fwd_persistent2) for N = 128, 256, 512, 1024; LSTM_HIP_FWD_FORM=1 keeps the first
+static bool fwd_second_form(int N) {
+    static const int form = getenv("LSTM_HIP_FWD_FORM") ? atoi(getenv("LSTM_HIP_FWD_FORM")) : 2;
+    return form != 1 && (N == 128 || N == 256 || N == 512 || N == 1024);
+}
+
 bool persistent_supported(int N, int B, int n_cus) {
     if (N % 64 != 0 || N > 1024) return false;
     const int NG = (B + 15) / 16;
-    int fb = 0, bb = 0;
+    int fb = 0, bb = 0, fwd_tiles = N / 4;
+    if (fwd_second_form(N)) {
+        fwd_tiles = N / 8;
+        switch (N / 128) {
+#define X(k) case k: fb = blocks_per_cu(k_fwd_persistent2<k, false>, 512); break;
+            X(1) X(2) X(4) X(8)
+#undef X
+        }
+    } else
     switch (N / 64) {
 #define X(k) case k: fb = blocks_per_cu(k_fwd_persistent<k, false>, 256); break;
         FWD_CASES(X)
@@ -992,12 +1129,25 @@ bool persistent_supported(int N, int B, int n_cus) {
     if (fb > 1) fb -= 1;
     if (bb > 1) bb -= 1;
     if (fb > 8) fb = 8;
-    return (size_t)(N / 4) * NG <= (size_t)fb * n_cus && (size_t)(N / 16) * NG <= (size_t)bb * n_cus;
+    return (size_t)fwd_tiles * NG <= (size_t)fb * n_cus && (size_t)(N / 16) * NG <= (size_t)bb * n_cus;
 }
 
 void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
                     const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B, bool fast,
                     hipStream_t st, unsigned long long *stamps) {
+    if (stamps == nullptr && fwd_second_form(N)) {
+        const dim3 grid2(N / 8, (B + 15) / 16), block2(512);
+        switch (N / 128) {
+#define X(k)                                                                                                          \
+    case k:                                                                                                           \
+        if (fast) hipLaunchKernelGGL((k_fwd_persistent2<k, true>), grid2, block2, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B); \
+        else hipLaunchKernelGGL((k_fwd_persistent2<k, false>), grid2, block2, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B);    \
+        break;
+            X(1) X(2) X(4) X(8)
+#undef X
+        }
+        return;
+    }
     const dim3 grid(N / 4, (B + 15) / 16), block(256);
     static const int stagger = getenv("LSTM_HIP_FWD_STAGGER") ? atoi(getenv("LSTM_HIP_FWD_STAGGER")) : 0;
     if (stamps != nullptr && N == 512) { // diagnostic build of the headline shape
