@@ -34,13 +34,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #pragma clang fp contract(off)
+// Gate math of the persistent kernels.  The default forms are built on v_exp_f32 / v_rcp_f32 (1 ulp each) with a
+// compensated argument, about 2 ulp overall against 1 ulp for the libm calls the per-step engine keeps (kernels.hip);
+// the gates sit on the hand-off chain, where the libm forms (IEEE division, branchy tanhf) cost ~300 cycles a step more.
+// tanh is (1-e)/(1+e), e = exp(-2|x|): its ABSOLUTE error stays below 1.2e-7; near zero the relative error does not.
+// tests/test_hip_parity.py::test_gate_math_accuracy pins both against float64.  FAST: plain v_exp of x*log2(e).
+__device__ __forceinline__ float p_exp_neg(float x) { // exp(-x)
+    const float hi = 1.44269502162933349609375f, lo = 1.925963033500011e-08f; // log2(e) = hi + lo
+    const float t = -x * hi;
+    const float r = __builtin_fmaf(-x, hi, -t) - x * lo; // -x*log2(e) = t + r
+    return __builtin_amdgcn_exp2f(t) * (1.0f + r * 0.693147180559945f);
+}
 template <bool FAST> __device__ __forceinline__ float p_sigm(float x) {
     if (FAST) return __frcp_rn(1.0f + __expf(-x));
-    return 1.0f / (1.0f + expf(-x));
+    return __builtin_amdgcn_rcpf(1.0f + p_exp_neg(x));
 }
 template <bool FAST> __device__ __forceinline__ float p_tanh(float x) {
     if (FAST) return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
-    return tanhf(x);
+    const float e = p_exp_neg(2.0f * __builtin_fabsf(x));
+    return __builtin_copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
 }
 
 // fragment loads kept in flight ahead of the MFMAs (see the pipelines below); -D overrides for A/B builds

@@ -112,6 +112,36 @@ def test_alternative_engines_agree(flag_name, oracle32):
     assert max(rep.values()) <= GRAD_TOL, rep
 
 
+def test_gate_math_accuracy():
+    """The persistent kernels' sigmoid / tanh (v_exp_f32 + v_rcp_f32 with a compensated argument, persistent.hip) against
+    float64 on a grid of pre-activations: one step with U = 0, b = 0, so gate pre-activation = the W column of the input."""
+    import lstm_hip
+    N, S, B = 128, 2, 16
+    sizes = [(4 * N, 256), (4 * N, N), (4 * N, 1), (256, N), (256, 1)]
+    rng = np.random.RandomState(3)
+    W = np.zeros((4 * N, 256), np.float32, order="F")
+    grid = np.concatenate([np.linspace(-30, 30, 4 * N * 8), rng.randn(4 * N * 6) * 2.0, rng.randn(4 * N * 2) * 1e-3])
+    rng.shuffle(grid)
+    W[:, :B] = grid.astype(np.float32).reshape(B, 4 * N).T
+    P = np.concatenate([W.ravel(order="F")] + [np.zeros(r * c, np.float32) for r, c in sizes[1:]])
+    xi = np.zeros((S, B), np.int32)
+    xi[1] = np.arange(B)
+    L = lstm_hip.Lstm(N, S, B)
+    L.set_params(P)
+    L.set_state(0, np.zeros((B, N), np.float32), np.zeros((B, N), np.float32))
+    L.set_window(xi, np.zeros((S, B), np.int32))
+    L.forward()
+    g, _ = L.get_activations(1)
+    _, c = L.get_state(1)
+    L.close()
+    pre = W[:, :B].T.astype(np.float64)  # [B, 4N]
+    sig = 1.0 / (1.0 + np.exp(-pre[:, :3 * N]))
+    assert np.max(np.abs(g[:, :3 * N] - sig) / sig) <= 4e-7          # relative: no cancellation in 1/(1+e)
+    assert np.max(np.abs(g[:, 3 * N:] - np.tanh(pre[:, 3 * N:]))) <= 1.5e-7   # absolute (see persistent.hip)
+    cref = np.tanh(g[:, :N].astype(np.float64) * g[:, 3 * N:].astype(np.float64))
+    assert np.max(np.abs(c - cref)) <= 1.5e-7
+
+
 def test_fast_math_flag_stays_close(oracle32):
     """LSTM_HIP_FAST_MATH swaps libm-accurate sigmoid/tanh for v_exp/v_rcp forms (the reference's
     --use_fast_math build): same results to 1e-4 of scale."""
