@@ -5,7 +5,8 @@
 //   lstm <text file> <hidden> <seq> <batch> <lr> [options]        (the reference's knobs, R/lstm.cc:53-63)
 //   lstm --data F --hidden N --seq S --batch B --lr LR [--epochs E] [--seed K] [--gpus G]
 //        [--windows W] [--sample C] [--lr-warmup-windows X] [--save PREFIX] [--load PREFIX]
-//        [--eval-file F] [--stride K] [--forget-bias V] [--fast-math] [--step-kernels] [--quiet]
+//        [--eval-file F] [--stride K] [--forget-bias V] [--test-percent F] [--test-every SEC] [--log PREFIX]
+//        [--fast-math] [--step-kernels] [--quiet]
 //
 // stdout follows the reference: "Read N bytes (file)" (R/lstm.cc:398), the carriage-return progress
 // line (OV/lstm_eigen_opt/lstm.cc:320-331), the epoch summary (R/lstm.cc:284-291: GFLOP uses 2^30,
@@ -14,6 +15,11 @@
 // --gpus G forks one process per GPU before anything touches HIP; batch streams are sharded
 // rank-major, the RCCL unique id travels over a pipe, and every window ends with one SUM
 // all-reduce of the flat gradient block inside the library.
+// --test-percent F holds out the last F% of the text (OV/lstm_eigen_class_CUDA/lstm.cc:76-86); --log PREFIX keeps the
+// reference's results log (class_CUDA lstm.cc:196-236): every --test-every seconds and at each epoch end a row
+// [index, seconds since the last test, train error, test error, GFlOP/s] is appended to PREFIX.txt, the parameters go
+// to PREFIX_{W,U,Why,b,by}.txt and 5000 sampled bytes to PREFIX_sample.txt.  --save / --load also carry the Adagrad
+// memory (PREFIX_mem_*.txt) and the stream cursors (PREFIX_cursors.txt), which the reference's checkpoints lack.
 // --lr-warmup-windows X applies lr = 0 for the first X windows (the reference's GPU driver uses
 // X = 50*S, OV/lstm_eigen_class_CUDA/lstm.cc:364-367; 0 = the root file's behaviour).
 #include "../../include/lstm_hip.h"
@@ -26,6 +32,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -46,7 +53,9 @@ struct Options {
     long lr_warmup = 0;
     int stride = 1;           // bytes per window per stream (lstm_segment.cc: S/2)
     double forget_bias = 0.0; // OV/lstm_eigen_class_batch/lstm.cc:81 uses 1
-    std::string save, load, eval_file;
+    std::string save, load, eval_file, log;
+    int test_percent = 0;    // last F%% of the text held out (OV/lstm_eigen_class_CUDA/lstm.cc:76-86 uses 1)
+    double test_every = 0.0; // seconds between held-out tests + log rows (class_CUDA: 900; 0 = at epoch end only)
     unsigned flags = 0;
     bool quiet = false;
 };
@@ -110,11 +119,11 @@ std::vector<Block> blocks(int N, int M) {
     add("by", M, 1);
     return b;
 }
-void save_params(const std::string &prefix, const std::vector<float> &P, int N, int M) {
+void save_params(const std::string &prefix, const std::vector<float> &P, int N, int M, int digits = 6) {
     for (const Block &b : blocks(N, M)) {
         std::ofstream f(prefix + "_" + b.name + ".txt");
         if (!f) die("cannot write " + prefix + "_" + b.name + ".txt");
-        f.precision(6);
+        f.precision(digits);
         for (size_t r = 0; r < b.rows; r++) {
             for (size_t c = 0; c < b.cols; c++) f << (c ? " " : "") << P[b.off + c * b.rows + r];
             f << "\n";
@@ -144,6 +153,52 @@ bool load_params(const std::string &prefix, std::vector<float> &P, int N, int M)
     return true;
 }
 
+
+// results log, OV/lstm_eigen_class_CUDA/lstm.cc:203-226 + io.h:16-30: the whole 5-column matrix is rewritten after
+// every test, printed the way Eigen's operator<< does (6 significant digits, one common column width)
+void write_results(const std::string &path, const std::vector<std::vector<double>> &rows) {
+    std::vector<std::vector<std::string>> cells;
+    size_t width = 0;
+    for (const auto &r : rows) {
+        cells.emplace_back();
+        for (double v : r) {
+            std::ostringstream ss;
+            ss.precision(6);
+            ss << (float)v;
+            width = std::max(width, ss.str().size());
+            cells.back().push_back(ss.str());
+        }
+    }
+    printf("Saving a matrix to %s... \n", path.c_str());
+    std::ofstream f(path);
+    if (!f) {
+        printf("file save error: (%s)\n", path.c_str());
+        return;
+    }
+    for (size_t r = 0; r < cells.size(); r++) {
+        for (size_t c = 0; c < cells[r].size(); c++)
+            f << (c ? " " : "") << std::string(width - cells[r][c].size(), ' ') << cells[r][c];
+        if (r + 1 < cells.size()) f << "\n";
+    }
+}
+void save_cursors(const std::string &prefix, const std::vector<uint64_t> &pos) {
+    std::ofstream f(prefix + "_cursors.txt");
+    if (!f) die("cannot write " + prefix + "_cursors.txt");
+    for (uint64_t v : pos) f << v << "\n";
+}
+bool load_cursors(const std::string &prefix, std::vector<uint64_t> &pos, size_t length, int S) {
+    std::ifstream f(prefix + "_cursors.txt");
+    if (!f) return false;
+    std::vector<uint64_t> v;
+    uint64_t x;
+    while (f >> x) v.push_back(x);
+    if (v.size() != pos.size()) return false; // written for another batch size: fall back to the spread start
+    for (uint64_t c : v)
+        if (c < (uint64_t)S || c >= length) return false;
+    pos = v;
+    return true;
+}
+
 Options parse(int argc, char **argv) {
     Options o;
     std::vector<std::string> pos;
@@ -169,13 +224,16 @@ Options parse(int argc, char **argv) {
         else if (a == "--save") o.save = val();
         else if (a == "--load") o.load = val();
         else if (a == "--eval-file") o.eval_file = val();
+        else if (a == "--log") o.log = val();
+        else if (a == "--test-percent") o.test_percent = atoi(val().c_str());
+        else if (a == "--test-every") o.test_every = atof(val().c_str());
         else if (a == "--fast-math") o.flags |= LSTM_HIP_FAST_MATH;
         else if (a == "--step-kernels") o.flags |= LSTM_HIP_STEP_KERNELS;
         else if (a == "--quiet") o.quiet = true;
         else if (a == "-h" || a == "--help") {
             printf("usage: lstm <text file> <hidden> <seq> <batch> <lr> [--epochs E --seed K --gpus G --windows W --sample C\n"
                    "            --lr-warmup-windows X --save PREFIX --load PREFIX --eval-file F --stride K --forget-bias V\n"
-                   "            --fast-math --step-kernels --quiet]\n");
+                   "            --test-percent F --test-every SEC --log PREFIX --fast-math --step-kernels --quiet]\n");
             exit(0);
         } else if (a.rfind("--", 0) == 0) die("unknown option " + a);
         else pos.push_back(a);
@@ -186,6 +244,7 @@ Options parse(int argc, char **argv) {
     if (pos.size() > 3) o.B = atoi(pos[3].c_str());
     if (pos.size() > 4) o.lr = atof(pos[4].c_str());
     if (o.gpus < 1 || o.B % o.gpus != 0) die("--batch must be a multiple of --gpus");
+    if (o.test_percent < 0 || o.test_percent > 50) die("--test-percent must be 0..50");
     return o;
 }
 
@@ -194,6 +253,13 @@ int run_rank(const Options &o, int rank, int up, int down) {
     const int M = LSTM_HIP_VOCAB, N = o.N, S = o.S, Bl = o.B / o.gpus;
     const bool lead = rank == 0;
     std::vector<uint8_t> data = rawread(o.data);
+    std::vector<uint8_t> testdata;
+    if (o.test_percent > 0) { // first (100-F)% trains, the rest is held out (OV/lstm_eigen_class_CUDA/lstm.cc:76-86)
+        const size_t percent_size = data.size() / 100, cut = (size_t)(100 - o.test_percent) * percent_size;
+        testdata.assign(data.begin() + cut, data.end());
+        data.resize(cut);
+        if (lead) printf("Train set size: %zu, Test set size: %zu, Total: %zu\n", data.size(), testdata.size(), data.size() + testdata.size());
+    }
     if (data.size() <= (size_t)S + 1) die("text too short");
     const size_t length = data.size();
 
@@ -228,16 +294,60 @@ int run_rank(const Options &o, int rank, int up, int down) {
         } else if (lead) printf("fopen error: (%s_W.txt) -- keeping the random initialisation\n", o.load.c_str());
     }
     CK(lstm_hip_set_params(h, 0, P.data()));
+    if (!o.load.empty()) { // resume: Adagrad memory, when the checkpoint has it
+        std::vector<float> mem(np, 0.0f);
+        if (std::ifstream(o.load + "_mem_W.txt").good() && load_params(o.load + "_mem", mem, N, M)) {
+            CK(lstm_hip_set_params(h, 2, mem.data()));
+            if (lead) printf("Loaded Adagrad memory from %s_mem_{W,U,Why,b,by}.txt\n", o.load.c_str());
+        }
+    }
     CK(lstm_hip_set_text(h, data.data(), length));
 
     // cursors: deterministic stand-in for rand() % (length - S) + S (OV/lstm_eigen_opt/lstm.cc:140-144)
-    std::vector<uint64_t> pos(Bl);
-    for (int b = 0; b < Bl; b++) pos[b] = (uint64_t)S + ((uint64_t)(rank * Bl + b) * (length - S)) / (uint64_t)o.B;
+    std::vector<uint64_t> start_all(o.B), pos(Bl); // start_all: every stream of the global batch, rank-major
+    for (int b = 0; b < o.B; b++) start_all[b] = (uint64_t)S + ((uint64_t)b * (length - S)) / (uint64_t)o.B;
+    if (!o.load.empty() && load_cursors(o.load, start_all, length, S) && lead) // resume: the streams' positions
+        printf("Loaded stream cursors from %s_cursors.txt\n", o.load.c_str());
+    std::copy(start_all.begin() + (size_t)rank * Bl, start_all.begin() + (size_t)(rank + 1) * Bl, pos.begin());
     CK(lstm_hip_set_cursors(h, pos.data()));
     CK(lstm_hip_reset_window(h));
     if (o.stride > 1) CK(lstm_hip_set_stride(h, o.stride, o.stride - 1)); // segment variant: carry from column seg-1
 
     const double flops_per_iteration = count_flops(M, N, S, o.B);
+
+    // held-out text: --eval-file wins over the --test-percent split
+    std::vector<uint8_t> evaldata = (lead && !o.eval_file.empty()) ? rawread(o.eval_file) : testdata;
+    const std::string evalname = !o.eval_file.empty() ? o.eval_file : "last " + std::to_string(o.test_percent) + "% of " + o.data;
+    std::vector<std::vector<double>> results;
+    double last_test = now();
+    SeededRng log_rng(o.seed + 7919u); // sampling for the log must not disturb the training stream
+    // test(p, testdata) + results row + checkpoint + sample file, OV/lstm_eigen_class_CUDA/lstm.cc:186-236 (lead rank only:
+    // the evaluator and the sampler are local to one handle, the other ranks wait at the next all-reduce)
+    auto test_and_log = [&](double train_error, double gflops) {
+        const double test_time = now() - last_test;
+        double test_error = NAN;
+        if (evaldata.size() > 1) CK(lstm_hip_eval_bits(h, evaldata.data(), evaldata.size(), &test_error));
+        printf("\nTrain error: %g, Test error: %g\n", train_error, test_error);
+        if (evaldata.size() > 1) printf("Test error: %.5f bits/char (%s)\n", test_error, evalname.c_str());
+        if (!o.log.empty()) {
+            results.push_back({(double)results.size(), test_time, train_error, test_error, gflops});
+            printf("%6g %6g %6g %6g %6g\n\n", results.back()[0], test_time, train_error, test_error, gflops);
+            write_results(o.log + ".txt", results);
+            CK(lstm_hip_get_params(h, 0, P.data()));
+            save_params(o.log, P, N, M);
+            const int n = 5000; // class_CUDA lstm.cc:229
+            std::vector<float> h0(N), c0(N);
+            log_rng.randn(h0.data(), N, 1, 0.0, 0.1);
+            log_rng.randn(c0.data(), N, 1, 0.0, 0.1);
+            std::vector<double> u(n);
+            for (double &x : u) x = log_rng.uniform();
+            std::vector<uint8_t> text(n);
+            CK(lstm_hip_sample(h, h0.data(), c0.data(), u.data(), n, text.data()));
+            std::ofstream f(o.log + "_sample.txt", std::ios::out | std::ios::binary);
+            f.write(reinterpret_cast<const char *>(text.data()), n);
+        }
+        last_test = now();
+    };
     const long windows_per_epoch = (o.windows > 0) ? o.windows : (long)((length - S + o.stride - 1) / o.stride);
     long done_windows = 0;
     std::vector<float> hs((size_t)N * o.B), cs((size_t)N * o.B);
@@ -270,6 +380,8 @@ int run_rank(const Options &o, int rank, int up, int down) {
             }
             i += chunk;
             done_windows += chunk;
+            if (lead && o.test_every > 0 && now() - last_test > o.test_every) // class_CUDA lstm.cc:186-188
+                test_and_log(epoch_loss / ((double)S * (double)i), (i * flops_per_iteration / std::pow(2.0, 30)) / (now() - t0));
             if (lead && !o.quiet) {
                 const double t1 = now();
                 printf("%9.2f%% %9.2f GFlOP/s\r", 100.0 * (double)(i + S) / (double)length,
@@ -294,14 +406,9 @@ int run_rank(const Options &o, int rank, int up, int down) {
             if (nan_windows > 0) // the reference skips NaN losses silently; the unshifted softmax (R/lstm.cc:199) overflows when lr is too large
                 printf("!!!! %ld of %ld windows had a NaN loss (skipped in the average): lower --lr or use --lr-warmup-windows\n",
                        nan_windows, windows_per_epoch);
-            if (!o.eval_file.empty()) {
-                std::vector<uint8_t> ev = rawread(o.eval_file);
-                double bits = 0.0;
-                if (ev.size() > 1) {
-                    CK(lstm_hip_eval_bits(h, ev.data(), ev.size(), &bits));
-                    printf("Test error: %.5f bits/char (%s)\n", bits, o.eval_file.c_str());
-                }
-            }
+            if (evaldata.size() > 1 || !o.log.empty())
+                test_and_log(epoch_loss / ((double)S * (double)(windows_per_epoch + S)),
+                             (flops_per_iteration * windows_per_epoch / std::pow(2.0, 30)) / epoch_time);
             if (o.sample > 0) { // R/lstm.cc:293-356
                 std::vector<float> h0(N), c0(N);
                 rng.randn(h0.data(), N, 1, 0.0, 0.1);
@@ -318,7 +425,18 @@ int run_rank(const Options &o, int rank, int up, int down) {
             if (!o.save.empty()) {
                 CK(lstm_hip_get_params(h, 0, P.data()));
                 save_params(o.save, P, N, M);
-                printf("Saved parameters to %s_{W,U,Why,b,by}.txt\n", o.save.c_str());
+                std::vector<float> mem(np);
+                CK(lstm_hip_get_params(h, 2, mem.data()));
+                save_params(o.save + "_mem", mem, N, M, 9);
+                std::vector<uint64_t> all(o.B); // every stream has advanced by the same number of bytes
+                const uint64_t span = (uint64_t)(length - S), adv = (uint64_t)done_windows * (uint64_t)o.stride;
+                for (int b = 0; b < o.B; b++) all[b] = (uint64_t)S + ((start_all[b] - S) + adv) % span;
+                std::vector<uint64_t> mine(Bl);
+                CK(lstm_hip_get_cursors(h, mine.data()));
+                for (int b = 0; b < Bl; b++)
+                    if (mine[b] != all[(size_t)rank * Bl + b]) die("cursor bookkeeping out of step with the library");
+                save_cursors(o.save, all);
+                printf("Saved parameters to %s_{W,U,Why,b,by}.txt (+ _mem_*, _cursors)\n", o.save.c_str());
             }
             fflush(stdout);
         }

@@ -59,3 +59,41 @@ def test_cli_rejects_bad_arguments():
     out = subprocess.run([LSTM, "/nonexistent.txt", "24", "5", "2", "0.1"], capture_output=True, text=True, timeout=60)
     assert out.returncode != 0
     assert "fopen error" in out.stdout or "too short" in out.stderr           # R/lstm.cc:416 wording
+
+
+def test_cli_results_log_holdout_and_resume(tmp_path, oracle32):
+    """--test-percent / --log (the reference's results log, OV/lstm_eigen_class_CUDA/lstm.cc:76-86,186-236) and a
+    resumable checkpoint: parameters + Adagrad memory + stream cursors."""
+    N, S, B, lr = 32, 8, 4, 0.05
+    text = _text(4000, seed=12)
+    f = tmp_path / "corpus.txt"
+    text.tofile(f)
+    log, ck = tmp_path / "run", tmp_path / "ck"
+    out = subprocess.run([LSTM, str(f), str(N), str(S), str(B), str(lr), "--epochs", "2", "--windows", "25", "--seed", "3",
+                          "--sample", "0", "--test-percent", "5", "--log", str(log), "--save", str(ck), "--quiet"],
+                         capture_output=True, text=True, errors="replace", timeout=120)
+    assert out.returncode == 0, out.stderr + out.stdout
+    cut = 95 * (len(text) // 100)
+    assert f"Train set size: {cut}, Test set size: {len(text) - cut}, Total: {len(text)}" in out.stdout
+    rows = np.loadtxt(str(log) + ".txt", ndmin=2)
+    assert rows.shape == (2, 5) and list(rows[:, 0]) == [0.0, 1.0]              # one row per epoch end
+    # the last row's test error is the held-out bits/char of the parameters saved beside it
+    P = np.concatenate([np.loadtxt(str(log) + f"_{k}.txt", ndmin=2).astype(np.float32).flatten(order="F")
+                        for k in ("W", "U", "b", "Why", "by")])
+    assert abs(rows[1, 3] - oracle32.eval_bits(N, 256, P, text[cut:])) <= 2e-3
+    assert os.path.getsize(str(log) + "_sample.txt") == 5000
+    # resumable checkpoint: memory is non-negative and non-zero, cursors advanced by the windows done
+    mem = np.loadtxt(str(ck) + "_mem_U.txt", ndmin=2)
+    assert mem.shape == (4 * N, N) and mem.min() >= 0 and mem.max() > 0
+    cur = np.loadtxt(str(ck) + "_cursors.txt", dtype=np.int64)
+    start = S + (np.arange(B) * (cut - S)) // B
+    assert list(cur) == list(S + (start - S + 50) % (cut - S))
+    out2 = subprocess.run([LSTM, str(f), str(N), str(S), str(B), str(lr), "--epochs", "1", "--windows", "10", "--sample", "0",
+                           "--test-percent", "5", "--load", str(ck), "--save", str(ck), "--quiet"],
+                          capture_output=True, text=True, errors="replace", timeout=120)
+    assert out2.returncode == 0, out2.stderr + out2.stdout
+    assert "Loaded Adagrad memory" in out2.stdout and "Loaded stream cursors" in out2.stdout
+    cur2 = np.loadtxt(str(ck) + "_cursors.txt", dtype=np.int64)
+    assert list(cur2) == list(S + (cur - S + 10) % (cut - S))
+    mem2 = np.loadtxt(str(ck) + "_mem_U.txt", ndmin=2)
+    assert np.all(mem2 >= mem * (1 - 1e-6))                                    # Adagrad memory only grows
