@@ -90,7 +90,7 @@ void softmax_loss_dy(float *Y, float *P, const float *by, const int32_t *ti, flo
 // window loss as the reference sums it: for each t a float sum over b, / B_global, accumulated in double;
 // when dby != null a second workgroup folds the per-wave partials into dby = rowsum(dY) (R/lstm.cc:227)
 void loss_reduce(const float *colloss, int steps, int B, int B_global, double *out, const float *dby_part, int n_parts,
-                 float *dby, hipStream_t st);
+                 float *dby, hipStream_t st, float scale = 1.0f);
 
 // ---- dW = DG * X^T and db = rowsum(DG)                                        (R/lstm.cc:251-252)
 // X is one-hot, so dW[:,v] is the sum of the DG columns whose input byte is v (bucket 256 = empty

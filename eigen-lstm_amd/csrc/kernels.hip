@@ -604,7 +604,7 @@ void softmax_loss_dy(float *Y, float *P, const float *by, const int32_t *ti, flo
 // block 0: window loss; blocks 1..4 (when dby != null): dby = rowsum(dY) from the per-wave partials, 64 rows each
 __global__ __launch_bounds__(1024) void k_loss_dby(const float *__restrict__ colloss, int steps, int B, int Bg,
                                                    double *__restrict__ out, const float *__restrict__ dby_part,
-                                                   int n_parts, float *__restrict__ dby) {
+                                                   int n_parts, float *__restrict__ dby, float scale) {
     __shared__ float4 red[16][64];
     if (blockIdx.x >= 1) { // 16 float4 row groups x 64 phases; phases folded in order
         const int m4 = (blockIdx.x - 1) * 16 + (threadIdx.x & 15), ph = threadIdx.x >> 4;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(1024) void k_loss_dby(const float *__restrict__ col
             s = (((((((s + v0) + v1) + v2) + v3) + v4) + v5) + v6) + v7;
         }
         for (; b < B; b++) s += cl[b];
-        acc += (double)(s / (float)Bg);
+        acc += (double)((s * scale) / (float)Bg); // scale: 1 (bits) or ln 2 (nats, last-step mode)
     }
     part[threadIdx.x] = acc;
     __syncthreads();
@@ -659,9 +659,9 @@ __global__ __launch_bounds__(1024) void k_loss_dby(const float *__restrict__ col
     }
 }
 void loss_reduce(const float *colloss, int steps, int B, int B_global, double *out, const float *dby_part, int n_parts,
-                 float *dby, hipStream_t st) {
+                 float *dby, hipStream_t st, float scale) {
     hipLaunchKernelGGL(k_loss_dby, dim3(dby ? 5 : 1), dim3(1024), 0, st, colloss, steps, B, B_global, out, dby_part,
-                       n_parts, dby);
+                       n_parts, dby, scale);
 }
 
 // ------------------------------------------------------------------------------------------------

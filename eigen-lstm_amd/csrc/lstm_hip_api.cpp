@@ -128,6 +128,7 @@ struct lstm_hip_ctx {
     unsigned long long *stamps = nullptr; // LSTM_HIP_DEBUG_STAMPS: [2][S][8] s_memtime values of the last forward
     unsigned long long *Hg = nullptr; // h_t as {value, tag} granules for the forward hand-off
     unsigned window_serial = 0;
+    int loss_mode = 0; // LSTM_HIP_LOSS_*
     unsigned fwd_epoch = 0, bwd_epoch = 0; // launches so far on the cumulative hand-off counters       // epoch_base = S * serial; tags of earlier windows never match
 
     void *comm = nullptr;
@@ -202,6 +203,14 @@ int check_abort(lstm_hip_ctx *h) {
 // steps already finished runs on `st2` behind k_wait_progress (forward: Y, softmax/loss/dY, DHy per
 // time chunk; backward: dWhy, the dW bucket sort, and dU one K-slice per time chunk).  Both streams
 // are joined before the function returns, so callers only ever see `st`.
+// reported loss: all S-1 steps in bits (R/lstm.cc:204-207) or the last step only in nats
+// (OV/lstm_eigen_class_CUDA/lstm.h:200-221); colloss holds -log2 p(target) per (step, column)
+const float *loss_src(const lstm_hip_ctx *h) {
+    return h->loss_mode == LSTM_HIP_LOSS_LAST_STEP_NATS ? h->colloss + (size_t)(h->cfg.S - 2) * h->cfg.B : h->colloss;
+}
+int loss_steps(const lstm_hip_ctx *h) { return h->loss_mode == LSTM_HIP_LOSS_LAST_STEP_NATS ? 1 : h->cfg.S - 1; }
+float loss_scale(const lstm_hip_ctx *h) { return h->loss_mode == LSTM_HIP_LOSS_LAST_STEP_NATS ? 0.693147180559945f : 1.0f; }
+
 bool overlap_now(const lstm_hip_ctx *h, int which /*1 fwd, 2 bwd*/) { return h->overlap && !h->profiling && (h->overlap_mask & which); }
 
 int launch_fwd_recurrence(lstm_hip_ctx *h) {
@@ -302,8 +311,8 @@ int do_backward(lstm_hip_ctx *h) {
     float *dY = h->Y + (size_t)256 * B;
     // dby = rowsum(dY) (R/lstm.cc:227): folded with the loss when the loop runs on the device
     if (!h->dby_done)
-        RUN(K_DBY, loss_reduce(h->colloss, S - 1, B, h->global_B, h->d_loss, h->dby_part, h->n_dby_parts,
-                               h->dP + h->pl.by, h->st));
+        RUN(K_DBY, loss_reduce(loss_src(h), loss_steps(h), B, h->global_B, h->d_loss, h->dby_part, h->n_dby_parts,
+                               h->dP + h->pl.by, h->st, loss_scale(h)));
     h->dby_done = false;
     // DHy = Why^T * dY                 R/lstm.cc:228, all steps (already done by the forward's followers in overlap mode)
     // fused mode: the backward recurrence produces DHy itself and accumulates dW, db, dWhy
@@ -647,7 +656,7 @@ int lstm_hip_loss(lstm_hip_t *h, double *loss_bits) {
     CHECK(h);
     if (!loss_bits) return fail(LSTM_HIP_EINVAL, "loss: null pointer");
     if (!h->fwd_done) return fail(LSTM_HIP_ESTATE, "loss called before forward");
-    RUN(K_LOSS, loss_reduce(h->colloss, h->cfg.S - 1, h->cfg.B, h->global_B, h->d_loss, nullptr, 0, nullptr, h->st));
+    RUN(K_LOSS, loss_reduce(loss_src(h), loss_steps(h), h->cfg.B, h->global_B, h->d_loss, nullptr, 0, nullptr, h->st, loss_scale(h)));
     HIP_TRY(hipMemcpyAsync(loss_bits, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
     return check_abort(h);
@@ -733,6 +742,13 @@ int lstm_hip_set_global_batch(lstm_hip_t *h, int32_t global_B) {
     return 0;
 }
 
+int lstm_hip_set_loss_mode(lstm_hip_t *h, int32_t mode) {
+    if (!h || (mode != LSTM_HIP_LOSS_ALL_STEPS_BITS && mode != LSTM_HIP_LOSS_LAST_STEP_NATS))
+        return fail(LSTM_HIP_EINVAL, "set_loss_mode: unknown mode %d", mode);
+    h->loss_mode = mode;
+    return 0;
+}
+
 int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, double *losses, float *elapsed_ms) {
     CHECK(h);
     if (count < 0) return fail(LSTM_HIP_EINVAL, "train_windows: count < 0");
@@ -755,8 +771,8 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
                                   h->cfg.S, h->cfg.B, h->cfg.N, h->stride, h->carry_col, h->st));
         int rc = 0;
         if ((rc = do_forward(h))) return rc;
-        RUN(K_LOSS, loss_reduce(h->colloss, h->cfg.S - 1, h->cfg.B, h->global_B, h->d_losses + i, h->dby_part,
-                                h->n_dby_parts, h->dP + h->pl.by, h->st));
+        RUN(K_LOSS, loss_reduce(loss_src(h), loss_steps(h), h->cfg.B, h->global_B, h->d_losses + i, h->dby_part,
+                                h->n_dby_parts, h->dP + h->pl.by, h->st, loss_scale(h)));
         h->dby_done = true;
         if ((rc = do_backward(h))) return rc;
         if ((rc = do_allreduce(h))) return rc;

@@ -25,6 +25,7 @@ DEBUG_STAMPS = 16
 NO_OVERLAP = 32
 NO_FUSED_GRADS = 64
 BF16_RECURRENCE = 128
+LOSS_ALL_STEPS_BITS, LOSS_LAST_STEP_NATS = 0, 1
 UNIQUE_ID_BYTES = 128
 VOCAB = 256
 
@@ -49,7 +50,7 @@ SYMBOLS = [
     "lstm_hip_set_window", "lstm_hip_slide_state", "lstm_hip_forward", "lstm_hip_loss", "lstm_hip_backward",
     "lstm_hip_adagrad", "lstm_hip_comm_unique_id", "lstm_hip_comm_init", "lstm_hip_allreduce_grads",
     "lstm_hip_set_text", "lstm_hip_set_cursors", "lstm_hip_get_cursors", "lstm_hip_reset_window",
-    "lstm_hip_get_window", "lstm_hip_train_windows", "lstm_hip_set_global_batch", "lstm_hip_set_stride", "lstm_hip_eval_bits",
+    "lstm_hip_get_window", "lstm_hip_train_windows", "lstm_hip_set_global_batch", "lstm_hip_set_loss_mode", "lstm_hip_set_stride", "lstm_hip_eval_bits",
     "lstm_hip_sample", "lstm_hip_synchronize", "lstm_hip_set_profiling", "lstm_hip_kernel_stat_count",
     "lstm_hip_kernel_stat", "lstm_hip_reset_kernel_stats", "lstm_hip_device_info", "lstm_hip_debug_stamps",
 ]
@@ -203,6 +204,10 @@ class Lstm:
 
     def set_global_batch(self, gb):
         _chk(self.lib.lstm_hip_set_global_batch(self._h, gb))
+
+    def set_loss_mode(self, mode):
+        """LOSS_ALL_STEPS_BITS (R/lstm.cc:204-207) or LOSS_LAST_STEP_NATS (OV/lstm_eigen_class_CUDA/lstm.h:200-221)."""
+        _chk(self.lib.lstm_hip_set_loss_mode(self._h, mode))
 
     # ---- device-resident loop ------------------------------------------------------------------
     def set_text(self, text):

@@ -136,6 +136,12 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
 int lstm_hip_set_stride(lstm_hip_t *h, int32_t stride, int32_t carry_col);
 /* global batch the loss is divided by (defaults to B; set by the host when streams are sharded) */
 int lstm_hip_set_global_batch(lstm_hip_t *h, int32_t global_B);
+/* what lstm_hip_loss / train_windows report: the sum over all S-1 steps in bits (R/lstm.cc:204-207, the default) or the
+ * last step only in nats (forward_loss of OV/lstm_eigen_class_CUDA/lstm.h:200-221).  The gradients do not change: that
+ * variant's backward still uses dy of every step (lstm.h:299-302). */
+#define LSTM_HIP_LOSS_ALL_STEPS_BITS 0
+#define LSTM_HIP_LOSS_LAST_STEP_NATS 1
+int lstm_hip_set_loss_mode(lstm_hip_t *h, int32_t mode);
 
 /* ---- held-out evaluator and sampler on the device (OV/lstm_eigen_class_CUDA/lstm.cc:661-720,
  *      578-659; R/lstm.cc:293-356).  eval: bits/char of `text` from h = c = 0.  sample: `count`

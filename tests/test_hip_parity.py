@@ -488,3 +488,32 @@ def test_bf16_flag_is_refused_where_unsupported():
     import lstm_hip
     with pytest.raises(lstm_hip.LstmHipError):
         lstm_hip.Lstm(64, 5, 8, flags=lstm_hip.BF16_RECURRENCE)   # N not a multiple of 128
+
+
+def test_last_step_loss_mode(oracle32):
+    """lstm_hip_set_loss_mode(LAST_STEP_NATS): forward_loss of OV/lstm_eigen_class_CUDA/lstm.h:200-221 -- only t = S-1,
+    natural log, divided by B; the gradients are those of the default mode (that variant's backward uses every dy)."""
+    import lstm_hip
+    N, S, B = 128, 9, 24
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=77)
+    fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
+    want = float(np.sum(-np.log(fw["probs"][S - 1][np.arange(B), ti[S - 1]].astype(np.float64))) / B)
+    L = lstm_hip.Lstm(N, S, B)
+    L.set_params(P)
+    L.set_state(0, h0, c0)
+    L.set_window(xi, ti)
+    L.forward()
+    bits_all = L.loss()
+    L.backward()
+    g0 = L.get_grads()
+    L.set_loss_mode(lstm_hip.LOSS_LAST_STEP_NATS)
+    L.forward()
+    got = L.loss()
+    L.backward()
+    g1 = L.get_grads()
+    with pytest.raises(lstm_hip.LstmHipError):
+        L.set_loss_mode(7)
+    L.close()
+    assert abs(bits_all - fw["loss_bits"]) <= LOSS_TOL * (S - 1)
+    assert abs(got - want) <= LOSS_TOL
+    assert np.array_equal(g0, g1)
