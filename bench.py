@@ -196,8 +196,12 @@ def main():
             calls, ms = mf[dom]
             avg_s = ms / calls * 1e-3
             ach = fl[dom] / avg_s / 1e12
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
+            # bf16 recurrence mode: the two recurrences run on the bf16 pipe (dense peak 2500 TFLOP/s); the PMC traffic
+            # file was collected for the fp32 kernels only
+            bf16_kernel = bool(args.flags & 128) and dom in ("fwd_persistent", "bwd_persistent")
+            peak = 2500.0 if bf16_kernel else PEAK_FP32_MFMA_TFLOPS
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None if bf16_kernel else pmc_traffic(dom),
                         "avg_launch_us": round(avg_s * 1e6, 2), "flop_per_launch": fl[dom],
                         "window_frac": round((24.0 * N * N + 6.0 * 256 * N) * (value / world) / 1e12
                                              / PEAK_FP32_MFMA_TFLOPS, 4)}

@@ -560,6 +560,129 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_bf16(const u32x4 *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 recurrence, second form (see k_fwd_persistent2): 8 units per workgroup, K over 8 waves, every loaded fragment
+// of bf16(h_{t-1}) feeds two MFMA tiles.  N = 256*NKS2.
+// ------------------------------------------------------------------------------------------------
+template <int NKS2, bool FAST>
+__global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__restrict__ Ufwd16, const float *__restrict__ W,
+                                                              const float *__restrict__ bias, float *__restrict__ H,
+                                                              unsigned short *Hb, float *__restrict__ C,
+                                                              float *__restrict__ G, const int32_t *__restrict__ xi,
+                                                              unsigned *cnt, unsigned *abortp, unsigned epoch, int S,
+                                                              int B) {
+    constexpr int N = 256 * NKS2, G4 = 4 * N;
+    __shared__ float red[8 * 2 * 4 * 64];
+    __shared__ int s_abort;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int NB2 = gridDim.x, NG = gridDim.y;
+    const int lin_ = blockIdx.x + NB2 * blockIdx.y;
+    const int p2 = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
+    const int q = l >> 4, c = l & 15;
+    const int col = 16 * g + c, colc = col < B ? col : B - 1;
+    const int p = 2 * p2 + (w & 1); // the row tile a gating wave (w < 2) finishes
+    const int j = 4 * p + q;
+
+    u32x4 a0[NKS2], a1[NKS2];
+#pragma unroll
+    for (int i = 0; i < NKS2; i++) {
+        a0[i] = Ufwd16[((size_t)(2 * p2) * (N / 32) + w * NKS2 + i) * 64 + l];
+        a1[i] = Ufwd16[((size_t)(2 * p2 + 1) * (N / 32) + w * NKS2 + i) * 64 + l];
+    }
+    float bs[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (w < 2) {
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
+        cprev = C[(size_t)colc * N + j];
+    }
+    const __amdgpu_buffer_rsrc_t rHb = make_rsrc(Hb, (size_t)S * N * B * sizeof(unsigned short));
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+
+    for (int t = 1; t < S; t++) {
+        float wx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w < 2) {
+            const int x = xi[t * B + colc];
+            if (x >= 0) {
+#pragma unroll
+                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
+            }
+        }
+        if (w == 0 && t > 1) {
+            const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
+            if (!wait_arrivals<FWD_SH>(cp, 2 * NB2, epoch, abortp, l) && l == 0) s_abort = 1;
+        }
+        __syncthreads();
+        if (s_abort) return;
+
+        u32x4 b[NKS2];
+        if (t == 1) { // the carry column exists only in fp32 (written before the launch): round it here
+            const float *hp = H + (size_t)colc * N + 32 * (w * NKS2) + 8 * q;
+#pragma unroll
+            for (int i = 0; i < NKS2; i++)
+                b[i] = pack_bf16x8(*reinterpret_cast<const float4 *>(hp + 32 * i), *reinterpret_cast<const float4 *>(hp + 32 * i + 4));
+        } else {
+            const int off = (int)((((size_t)(t - 1) * B + colc) * N + 32 * (w * NKS2) + 8 * q) * sizeof(unsigned short));
+#pragma unroll
+            for (int i = 0; i < NKS2; i++) b[i] = __builtin_amdgcn_raw_buffer_load_b128(rHb, off + 64 * i, 0, 16);
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NKS2; i++) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0[i]), __builtin_bit_cast(bf16x8, b[i]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[i]), __builtin_bit_cast(bf16x8, b[i]), acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            red[((w * 2 + 0) * 4 + r) * 64 + l] = acc0[r];
+            red[((w * 2 + 1) * 4 + r) * 64 + l] = acc1[r];
+        }
+        __syncthreads();
+
+        if (w < 2) {
+            float pre[4];
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) {
+                float uh = red[((0 * 2 + w) * 4 + gt) * 64 + l];
+#pragma unroll
+                for (int ww = 1; ww < 8; ww++) uh += red[((ww * 2 + w) * 4 + gt) * 64 + l];
+                pre[gt] = (wx[gt] + uh) + bs[gt]; // R/lstm.cc:176
+            }
+            const float ig = p_sigm<FAST>(pre[0]), og = p_sigm<FAST>(pre[1]), fg = p_sigm<FAST>(pre[2]); // :179
+            const float ug = p_tanh<FAST>(pre[3]);                                                        // :182
+            const float cv = p_tanh<FAST>(ig * ug + fg * cprev);                                          // :185-189
+            const float hv = og * cv;                                                                     // :192
+            cprev = cv;
+            float4 h4;
+            h4.x = __shfl(hv, c, 64);
+            h4.y = __shfl(hv, 16 + c, 64);
+            h4.z = __shfl(hv, 32 + c, 64);
+            h4.w = __shfl(hv, 48 + c, 64);
+            if (q == 0 && col < B) { // the hand-off copy: 4 units as bf16 = one 8-byte sc1 store
+                const unsigned long long pk = (unsigned long long)pack_bf16x2(h4.x, h4.y) |
+                                              ((unsigned long long)pack_bf16x2(h4.z, h4.w) << 32);
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(Hb + ((size_t)t * B + col) * N + 4 * p), pk,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (t + 1 < S) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (l == 0)
+                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * CNT_SLOTS + (p & (FWD_SH - 1))) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (col < B) {
+                if (q == 0) *reinterpret_cast<float4 *>(H + ((size_t)t * B + col) * N + 4 * p) = h4;
+                float *gc = G + ((size_t)t * B + col) * G4 + j;
+                gc[0] = ig;
+                gc[N] = og;
+                gc[2 * N] = fg;
+                gc[3 * N] = ug;
+                C[((size_t)t * B + col) * N + j] = cv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward recurrence, granule hand-off (LSTM_HIP_GRANULE_HANDOFF; measured slower).  Same decomposition and arithmetic as
 // k_fwd_persistent, but h_t travels as 8-byte {tag, value} granules (Guideline 16, recipe R2: the data
 // IS the flag): the producing lane writes ONE aligned 8-byte sc1 store per value and moves on -- no
@@ -1204,8 +1327,21 @@ size_t bwd_partial_floats(int N) { return (size_t)4 * N * 256 + (size_t)4 * N * 
 void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, float *H, unsigned short *Hb, float *C,
                          float *G, const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
                          bool fast, hipStream_t st) {
-    const dim3 grid(N / 4, (B + 15) / 16), block(256);
     const u32x4 *U16 = reinterpret_cast<const u32x4 *>(Ufwd16);
+    if (fwd_second_form(N) && N % 256 == 0) {
+        const dim3 grid2(N / 8, (B + 15) / 16), block2(512);
+        switch (N / 256) {
+#define X(k)                                                                                                             \
+    case k:                                                                                                              \
+        if (fast) hipLaunchKernelGGL((k_fwd_persistent2_bf16<k, true>), grid2, block2, 0, st, U16, W, bias, H, Hb, C, G, xi, cnt, abortp, epoch, S, B); \
+        else hipLaunchKernelGGL((k_fwd_persistent2_bf16<k, false>), grid2, block2, 0, st, U16, W, bias, H, Hb, C, G, xi, cnt, abortp, epoch, S, B);    \
+        break;
+            X(1) X(2) X(4)
+#undef X
+        }
+        return;
+    }
+    const dim3 grid(N / 4, (B + 15) / 16), block(256);
     switch (N / 128) {
 #define X(k)                                                                                                             \
     case k:                                                                                                              \
