@@ -50,7 +50,8 @@ void fwd_persistent_granules(const float4 *Ufwd, const float *W, const float *bi
                               int S, int B, bool fast, hipStream_t st);
 // follower support: a 1-wave kernel that returns once step `t` of launch `epoch` has been published by all
 // `n_prod` producers of every column group (or the abort word is set)
-void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, unsigned *abortp, hipStream_t st);
+void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, unsigned *abortp, hipStream_t st,
+                   bool backward = false, int arrivals = 1);
 // gpart != null (8-column groups only): fused mode.  The recurrence then also produces DHy on the fly from
 // Why and dY (DHy is not read), and leaves per-column-group partial blocks [dW | - | db | dWhy]
 // (bwd_partial_floats(N) floats each) to be folded in group order; H and xi are read as well.

@@ -316,7 +316,7 @@ int do_backward(lstm_hip_ctx *h) {
     h->dby_done = false;
     // DHy = Why^T * dY                 R/lstm.cc:228, all steps (already done by the forward's followers in overlap mode)
     // fused mode: the backward recurrence produces DHy itself and accumulates dW, db, dWhy
-    const bool fused = h->persistent && h->gpart != nullptr && !h->stamps && h->bwd_cols == 8 && !overlap_now(h, 2);
+    const bool fused = h->persistent && h->gpart != nullptr && h->bwd_cols == 8 && !overlap_now(h, 2);
     if (!h->dhy_done && !fused)
         RUN(K_GEMM_DHY, gemm(true, false, N, T, 256, h->P + h->pl.Why, 256, dY, 256, h->DHy + (size_t)N * B, N, 1, nullptr,
                              h->st));
@@ -341,7 +341,7 @@ int do_backward(lstm_hip_ctx *h) {
         // (otherwise the dispatcher packs recurrence workgroups unevenly around them and the whole
         // chain runs at the pace of the most crowded CU): the first published step proves that.
         const int NGb = (B + h->bwd_cols - 1) / h->bwd_cols;
-        if (S - 1 >= 2) wait_progress(cb, S - 1, NGb, N / 16, h->bwd_epoch, h->abortp, h->st2);
+        if (S - 1 >= 2) wait_progress(cb, S - 1, NGb, N / 16, h->bwd_epoch, h->abortp, h->st2, true, h->bwd_cols / 4);
         // independent of the recurrence: dWhy = dY * H^T (R/lstm.cc:226) and the dW bucket sort
         gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256, h->splits_dWhy, h->slabs,
              h->st2);
@@ -350,7 +350,7 @@ int do_backward(lstm_hip_ctx *h) {
         const int kchunk = h->chunk_steps * B, nz = (S - 1 + h->chunk_steps - 1) / h->chunk_steps;
         for (int z = nz - 1; z >= 0; z--) {
             const int ta = z * h->chunk_steps + 1; // earliest step of the slice = last one the recurrence reaches
-            if (ta >= 2) wait_progress(cb, ta, NGb, N / 16, h->bwd_epoch, h->abortp, h->st2);
+            if (ta >= 2) wait_progress(cb, ta, NGb, N / 16, h->bwd_epoch, h->abortp, h->st2, true, h->bwd_cols / 4);
             else HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_main, 0)); // step 1 publishes nothing
             gemm_slice(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->slabs_dU, kchunk, z, h->st2);
         }

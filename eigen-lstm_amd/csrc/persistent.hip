@@ -55,6 +55,11 @@ template <bool FAST> __device__ __forceinline__ float p_tanh(float x) {
     return __builtin_copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
 }
 
+// DPP lane move (quad_perm / row shifts): the value of `v` in the lane the control word names; all lanes must be active
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
 // fragment loads kept in flight ahead of the MFMAs (see the pipelines below); -D overrides for A/B builds
 #ifndef BWD_PF
 #define BWD_PF 6
@@ -873,7 +878,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     __shared__ float red[8 * 4 * 64];
     __shared__ __attribute__((aligned(16))) float stage[2][16 * 4 * 16]; // dg of this WG, double-buffered by step parity
     __shared__ int s_abort;
-    __shared__ unsigned s_pair; // arrivals of the elementwise waves at their private sync points
     // FUSE: output-layer followers (waves 4..7): DHy_t = Why^T * dy_t for this workgroup's units, one step
     // ahead of its use, and the dWhy columns of those units
     __shared__ float olred[4 * 4 * 64];
@@ -892,8 +896,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     const int jj = tid & 15, cc = (tid >> 4) & (COLS - 1);
     const int ecol = COLS * g + cc, ecolc = ecol < B ? ecol : B - 1;
     const int j = 16 * kb + jj;
-    // store role (threads 0..ETH-1): float4 of 4 consecutive units for (column sc, gate sg)
-    const int sc = (tid >> 4) & (COLS - 1), sg = (tid >> 2) & 3, sq = tid & 3;
 
     float4 a[NRS];
 #pragma unroll
@@ -907,10 +909,9 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
         for (int i = tid; i < 257 * 64; i += 512) dWt[i] = 0.0f;
     if (tid == 0) {
         s_abort = 0;
-        s_pair = 0;
         s_ol = 0;
     }
-    unsigned pair_target = 0, ol_target = 0;
+    unsigned ol_target = 0;
     // Why^T A-fragments of the follower waves: wave ow = w-4 takes output rows m in [64*ow, 64*ow+64);
     // fragment i of k-step ks4 is Why[m = 64*ow + 16*ks4 + 4*(l>>4) + i][16*kb + (l&15)]
     float4 wa[FUSE ? 4 : 1];
@@ -933,15 +934,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
         for (int i = 0; i < g * (stagger & 255); i++) __builtin_amdgcn_s_sleep(32); // see k_fwd_persistent
 
     // sync point of the EW elementwise waves only (LDS counter; LDS operations of a wave complete in order)
-    auto pair_sync = [&]() {
-        pair_target += EW;
-        if (EW > 1) {
-            if (l == 0) __hip_atomic_fetch_add(&s_pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            while (__hip_atomic_load(&s_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < pair_target) {
-            }
-        }
-        asm volatile("" ::: "memory");
-    };
     // dW[:, x] += dg[:, col] (R/lstm.cc:251) for the step whose dg sits in stage[par]: wave EW, one thread per
     // row, walking the columns in order (deterministic); tu is that step
     auto update = [&](int par, int tu) {
@@ -956,7 +948,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
             const float *sg_ = stage[par];
             const int gt = l >> 4, rj = l & 15;
 #pragma unroll
-            for (int c = 0; c < COLS; c++)
+            for (int c = 0; c < COLS; c++) // (LDS float atomics instead of read-add-write: 481 -> 523 us)
                 if (xs[c] >= 0) dWt[xs[c] * 64 + l] += sg_[(c * 4 + gt) * 16 + rj];
         }
     };
@@ -967,8 +959,8 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     auto ol_sync = [&]() {
         ol_target += 4;
         if (l == 0) __hip_atomic_fetch_add(&s_ol, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(&s_ol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ol_target) {
-        }
+        while (__hip_atomic_load(&s_ol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ol_target)
+            ;
         asm volatile("" ::: "memory");
     };
     // operands are fetched a whole chain phase ahead of their use (the followers must not arrive late at
@@ -1053,7 +1045,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
         if (FUSE && w >= 4 && t >= 2) output_layer_fetch(t - 1);
         if (has_next && w == 0) {
             const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
-            if (!wait_arrivals<BWD_SH>(cpn, NBK, epoch, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
+            if (!wait_arrivals<BWD_SH>(cpn, NBK, epoch * EW, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
         }
         __syncthreads();
         if (s_abort) return;
@@ -1126,35 +1118,64 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                 dbacc[2] += d_f;
                 dbacc[3] += d_u;
             }
-            float *sp = stage[cur] + (cc * 4) * 16 + jj;
-            sp[0] = d_i;
-            sp[16] = d_o;
-            sp[32] = d_f;
-            sp[48] = d_u;
-            pair_sync();
+            // 4x4 transpose over the four lanes of a quad by DPP (no LDS: the follower waves keep the LDS queue busy at this
+            // point, and four staged writes + a read cost ~900 cycles here): lane (column cc, unit jj = 4*tq + ta) ends
+            // up with gate ta of units 4*tq .. 4*tq+3, one 16-byte store
+            const int ta = jj & 3, tq = jj >> 2;
+            float t0 = d_i, t1 = d_o, t2 = d_f, t3 = d_u;
+            {
+                const float lo = (ta & 1) ? t0 : t1, hi = (ta & 1) ? t2 : t3;
+                const float rlo = dpp_f<0xB1>(lo), rhi = dpp_f<0xB1>(hi); // quad_perm [1,0,3,2]
+                if (ta & 1) {
+                    t0 = rlo;
+                    t2 = rhi;
+                } else {
+                    t1 = rlo;
+                    t3 = rhi;
+                }
+                const float s0 = (ta & 2) ? t0 : t2, s1 = (ta & 2) ? t1 : t3;
+                const float r0 = dpp_f<0x4E>(s0), r1 = dpp_f<0x4E>(s1); // quad_perm [2,3,0,1]
+                if (ta & 2) {
+                    t0 = r0;
+                    t1 = r1;
+                } else {
+                    t2 = r0;
+                    t3 = r1;
+                }
+            }
             BSTAMP_AT(3)
-            const int scol = COLS * g + sc;
-            if (scol < B) {
-                const float4 v = *reinterpret_cast<const float4 *>(stage[cur] + (sc * 4 + sg) * 16 + 4 * sq);
+            const float4 v = {t0, t1, t2, t3};
+            float4 v2 = v;
+            if (BF16) { // the next quad's four units of the same gate: lane + 4 within the row of 16 (row_shl:4)
+                v2.x = dpp_f<0x104>(t0);
+                v2.y = dpp_f<0x104>(t1);
+                v2.z = dpp_f<0x104>(t2);
+                v2.w = dpp_f<0x104>(t3);
+            }
+            if (ecol < B) {
                 if (BF16) { // fp32 copy for the dU product (read after the launch); bf16 copy is the hand-off
-                    *reinterpret_cast<float4 *>(DG + ((size_t)t * B + scol) * G4 + sg * N + 16 * kb + 4 * sq) = v;
-                    if ((sq & 1) == 0) {
-                        const float4 v2 = *reinterpret_cast<const float4 *>(stage[cur] + (sc * 4 + sg) * 16 + 4 * sq + 4);
+                    *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
+                    if ((tq & 1) == 0)
                         __builtin_amdgcn_raw_buffer_store_b128(
                             pack_bf16x8(v, v2), rDG,
-                            (int)((((size_t)t * B + scol) * G4 + sg * N + 16 * kb + 4 * sq) * sizeof(unsigned short)), 0, 16);
-                    }
+                            (int)((((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) * sizeof(unsigned short)), 0, 16);
                 } else {
-                    st_sc1(v, rDG, (int)((((size_t)t * B + scol) * G4 + sg * N + 16 * kb + 4 * sq) * sizeof(float)));
+                    st_sc1(v, rDG, (int)((((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) * sizeof(float)));
                 }
             }
             if (t > 1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the signal
-                pair_sync();
-                BSTAMP_AT(4)
-                if (tid == 0)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains, then signals for itself:
+                BSTAMP_AT(4)                                     // EW arrivals per workgroup and step
+                if (l == 0)
                     __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * CNT_SLOTS + (kb & (BWD_SH - 1))) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (FUSE) { // dg_t for the dW follower (read after the next workgroup barrier): off the chain
+                float *sp = stage[cur] + (cc * 4) * 16 + jj;
+                sp[0] = d_i;
+                sp[16] = d_o;
+                sp[32] = d_f;
+                sp[48] = d_u;
             }
         } else if (FUSE) {
             if (w == EW && has_next) update(cur ^ 1, t + 1); // dg_{t+1}, published a step ago; off the critical path
@@ -1204,13 +1225,18 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
 // every column group's counters show that step t has been published; kernels queued behind it on the
 // same stream then read data that was written through (sc1) before the counters moved.
 // ------------------------------------------------------------------------------------------------
+template <int SH>
 __global__ __launch_bounds__(64) void k_wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch,
                                                       unsigned *abortp) {
     for (int g = 0; g < NG; g++)
-        if (!wait_arrivals<FWD_SH>(cnt + (size_t)(t * NG + g) * CNT_SLOTS * CNT_STRIDE, n_prod, epoch, abortp, threadIdx.x)) return;
+        if (!wait_arrivals<SH>(cnt + (size_t)(t * NG + g) * CNT_SLOTS * CNT_STRIDE, n_prod, epoch, abortp, threadIdx.x)) return;
 }
-void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, unsigned *abortp, hipStream_t st) {
-    hipLaunchKernelGGL(k_wait_progress, dim3(1), dim3(64), 0, st, cnt, t, NG, n_prod, epoch, abortp);
+// backward = false: the forward counters (one arrival per row tile of 4 units); true: the backward counters, where every
+// elementwise wave of a workgroup arrives for itself (`arrivals` per workgroup)
+void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, unsigned *abortp, hipStream_t st, bool backward,
+                   int arrivals) {
+    if (backward) hipLaunchKernelGGL(k_wait_progress<BWD_SH>, dim3(1), dim3(64), 0, st, cnt, t, NG, n_prod, epoch * arrivals, abortp);
+    else hipLaunchKernelGGL(k_wait_progress<FWD_SH>, dim3(1), dim3(64), 0, st, cnt, t, NG, n_prod, epoch, abortp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1390,7 +1416,8 @@ void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float
                            cnt, abortp, epoch, S, B, stagger, stamps);                                                     \
     } while (0)
     if (stamps != nullptr && N == 512) {
-        if (cols == 8) BWD_LAUNCH(16, 8, false, true);
+        if (cols == 8 && fuse) BWD_LAUNCH(16, 8, true, true);
+        else if (cols == 8) BWD_LAUNCH(16, 8, false, true);
         else BWD_LAUNCH(16, 16, false, true);
         return;
     }
