@@ -43,13 +43,32 @@ __device__ __forceinline__ float wave_sum(float v) {
 //        tile rows are ordered (hidden unit, gate) so that one lane ends up holding i,o,f,u of ONE
 //        hidden unit in its four accumulator registers (row = 4*(l>>4) + reg  ->  reg = gate).
 //   Ubwd[kb][r4][l].i = U[16*r4 + 4*(l>>4) + i][16*kb + (l&15)]          (A = U^T, 16 hidden per tile)
+//   Ubwd4[kb][w][m][l].z' (optional; the 4x4x1 form of the backward recurrence, k_bwd_persistent<.., M4>): wave w of
+//        workgroup kb owns gate rows [Kw*w, Kw*(w+1)), Kw = N/2; lane l = 32x' + 16y + 4z + j;
+//        = U[Kw*w + 32*(m>>1) + 4*(2z' + y) + 2*(m&1) + x'][16*kb + 4z + j]
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t ubwd4_index(int gk, int hr, int N) { // float index of U[gk][hr] in Ubwd4
+    const int Kw = N / 2, w = gk / Kw, kk = gk % Kw, rem = kk & 31;
+    const int m = 2 * (kk >> 5) + ((rem >> 1) & 1), xp = rem & 1, y = (rem >> 2) & 1, zp = rem >> 3;
+    const int l = 32 * xp + 16 * y + (hr & 15);
+    return ((((size_t)(hr >> 4) * 8 + w) * (N / 32) + m) * 64 + l) * 4 + zp;
+}
 __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, float4 *__restrict__ Ufwd,
-                                                float4 *__restrict__ Ubwd, int N) {
+                                                float4 *__restrict__ Ubwd, float4 *__restrict__ Ubwd4, int N) {
     const int G4 = 4 * N;
     const size_t nf4 = (size_t)N * N; // float4 count of each image (4N*N floats)
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < 2 * nf4; e += (size_t)gridDim.x * blockDim.x) {
-        if (e < nf4) {
+    const size_t total = (Ubwd4 ? 3 : 2) * nf4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        if (e >= 2 * nf4) { // one float4 of U (4 gate rows of one hidden column) -> four scalars of Ubwd4
+            const size_t e3 = e - 2 * nf4;
+            const int r = 4 * (int)(e3 % N), k = (int)(e3 / N);
+            const float4 p = *reinterpret_cast<const float4 *>(U + (size_t)k * G4 + r);
+            float *u4 = reinterpret_cast<float *>(Ubwd4);
+            u4[ubwd4_index(r + 0, k, N)] = p.x;
+            u4[ubwd4_index(r + 1, k, N)] = p.y;
+            u4[ubwd4_index(r + 2, k, N)] = p.z;
+            u4[ubwd4_index(r + 3, k, N)] = p.w;
+        } else if (e < nf4) {
             int l = (int)(e & 63);
             size_t q = e >> 6;
             int k4 = (int)(q % (N / 16)), jb = (int)(q / (N / 16));
@@ -72,11 +91,11 @@ __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, flo
         }
     }
 }
-void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st) {
-    size_t n = 2 * (size_t)N * N;
+void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, float4 *Ubwd4) {
+    size_t n = (Ubwd4 ? 3 : 2) * (size_t)N * N;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_pack_U, dim3(blocks), dim3(256), 0, st, U, Ufwd, Ubwd, N);
+    hipLaunchKernelGGL(k_pack_U, dim3(blocks), dim3(256), 0, st, U, Ufwd, Ubwd, Ubwd4, N);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -954,7 +973,8 @@ __device__ __forceinline__ float adagrad1(float p, float d, float &m, float lr) 
 // rows of one column k of U: one float4 of Ubwd, four scalars of Ufwd.
 __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const float *__restrict__ dP,
                                                  float *__restrict__ mem, size_t n4, float lr, size_t u_off4, int N,
-                                                 float4 *__restrict__ Ufwd, float4 *__restrict__ Ubwd) {
+                                                 float4 *__restrict__ Ufwd, float4 *__restrict__ Ubwd,
+                                                 float4 *__restrict__ Ubwd4) {
     const size_t u_n4 = (size_t)N * N; // float4 count of U
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 p = reinterpret_cast<float4 *>(P)[i];
@@ -971,6 +991,13 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const fl
             const int r = 4 * (int)(e % N), k = (int)(e / N);
             // Ubwd[kb][r4][l] = U[16*r4 + 4*(l>>4) + 0..3][16*kb + (l&15)]
             Ubwd[((size_t)(k >> 4) * (N / 4) + (r >> 4)) * 64 + (((r & 15) >> 2) << 4) + (k & 15)] = p;
+            if (Ubwd4 != nullptr) {
+                float *u4 = reinterpret_cast<float *>(Ubwd4);
+                u4[ubwd4_index(r + 0, k, N)] = p.x;
+                u4[ubwd4_index(r + 1, k, N)] = p.y;
+                u4[ubwd4_index(r + 2, k, N)] = p.z;
+                u4[ubwd4_index(r + 3, k, N)] = p.w;
+            }
             // Ufwd[jb][k4][l].i = U[(l&3)*N + 4*jb + ((l&15)>>2)][16*k4 + 4*(l>>4) + i]
             const int gate = r / N, hid = r % N; // 4 rows share the gate (N % 4 == 0)
             const int k4 = k >> 4, kq = (k & 15) >> 2, ki = k & 3;
@@ -986,11 +1013,11 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const fl
     }
 }
 void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
-             hipStream_t st) {
+             hipStream_t st, float4 *Ubwd4) {
     const size_t n4 = n / 4; // the flat block is a multiple of 4 floats (M = 256, N % 16 == 0)
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adagrad, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd);
+    hipLaunchKernelGGL(k_adagrad, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4);
 }
 
 // ------------------------------------------------------------------------------------------------

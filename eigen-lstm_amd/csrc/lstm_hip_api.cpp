@@ -102,6 +102,7 @@ struct lstm_hip_ctx {
 
     float *P = nullptr, *dP = nullptr, *mem = nullptr;
     float4 *Ufwd = nullptr, *Ubwd = nullptr;
+    float4 *Ubwd4 = nullptr; // weight image of the 4x4x1 backward form (kernels.hip, k_pack_U), when bwd_uses_m4
     bool packed = false;
     float *H = nullptr, *C = nullptr, *G = nullptr, *DG = nullptr, *Y = nullptr, *Pr = nullptr, *DHy = nullptr;
     float *dcnext = nullptr, *colloss = nullptr, *dby_part = nullptr, *slabs = nullptr;
@@ -262,7 +263,7 @@ int do_forward(lstm_hip_ctx *h) {
     const int N = h->cfg.N, B = h->cfg.B, S = h->cfg.S, G4 = 4 * N;
     const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
     if (!h->packed) {
-        RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd, h->Ubwd, N, h->st));
+        RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd, h->Ubwd, N, h->st, h->Ubwd4));
         h->packed = true;
     }
     h->n_dby_parts = softmax_parts(h->T);
@@ -334,7 +335,7 @@ int do_backward(lstm_hip_ctx *h) {
         HIP_TRY(hipEventRecord(h->ev_fork, h->st));
         HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
         if (h->st_b) HIP_TRY(hipStreamWaitEvent(h->st_b, h->ev_fork, 0));
-        bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, nullptr, nullptr, nullptr, cb, h->abortp,
+        bwd_persistent(h->Ubwd4 ? h->Ubwd4 : h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, nullptr, nullptr, nullptr, cb, h->abortp,
                        h->bwd_epoch, N, S, B, h->bwd_cols, sb);
         HIP_TRY(hipEventRecord(h->ev_main, sb));
         // Followers must not be dispatched before every workgroup of the recurrence has been placed
@@ -366,7 +367,7 @@ int do_backward(lstm_hip_ctx *h) {
                                               h->xi, fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp,
                                               h->bwd_epoch, N, S, B, 8, h->st, nullptr, h->DGb));
         else
-        RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr,
+        RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd4 ? h->Ubwd4 : h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr,
                                           h->P + h->pl.Why, dY, cb, h->abortp, h->bwd_epoch, N, S, B, h->bwd_cols, h->st,
                                           h->stamps ? h->stamps + (size_t)2 * S * 8 : nullptr));
     } else {
@@ -408,7 +409,7 @@ int do_allreduce(lstm_hip_ctx *h) {
 }
 
 int do_adagrad(lstm_hip_ctx *h, double lr) {
-    RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd, h->Ubwd, h->st));
+    RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd, h->Ubwd, h->st, h->Ubwd4));
     h->packed = true; // the U images were refreshed by the same launch
     h->packed16 = false;
     return 0;
@@ -508,6 +509,7 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
         HIP_TRY(hipMalloc(&h->Ufwd16, (size_t)8 * N * N));
         HIP_TRY(hipMalloc(&h->Ubwd16, (size_t)8 * N * N));
     }
+    if (h->persistent && bwd_uses_m4((int)N, h->bwd_cols, h->bf16)) ALLOC(h->Ubwd4, N * N);
     if (h->persistent && !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512) // larger N: the dU tiles no longer fit the VGPRs
         ALLOC(h->gpart, (size_t)((B + h->bwd_cols - 1) / h->bwd_cols) * bwd_partial_floats(cfg->N));
     // followers need whole MFMA k-tiles and whole softmax waves per time chunk
@@ -539,7 +541,7 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     (void)hipStreamSynchronize(h->st);
     if (h->st2) (void)hipStreamSynchronize(h->st2);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-    void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
+    void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->Ubwd4, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
                     h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->Hg, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);

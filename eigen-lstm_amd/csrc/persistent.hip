@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_g(const float4 *__restri
 // gradient block) in gpart[g]; gemm_fold adds the groups in order afterwards.
 // (Accumulating dU the same way -- 4 x N/16 MFMA accumulator tiles per workgroup -- was built and
 // measured: it needs ~100 more VGPRs, spills, and cost more than the separate GEMM it replaced.)
-template <int NR4W, int COLS, bool FUSE, bool STAMP = false, bool BF16 = false>
+template <int NR4W, int COLS, bool FUSE, bool STAMP = false, bool BF16 = false, bool M4 = false>
 __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restrict__ Ubwd, float *DG,
                                                            const float *__restrict__ DHy, const float *__restrict__ G,
                                                            const float *__restrict__ C, const float *__restrict__ H,
@@ -900,7 +900,9 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     float4 a[NRS];
 #pragma unroll
     for (int i = 0; i < NRS; i++)
-        a[i] = BF16 ? Ubwd[((size_t)kb * (G4 / 32) + w * NRS + i) * 64 + l] : Ubwd[((size_t)kb * nr4 + w * NR4W + i) * 64 + l];
+        a[i] = BF16 ? Ubwd[((size_t)kb * (G4 / 32) + w * NRS + i) * 64 + l]
+               : M4 ? Ubwd[(((size_t)kb * 8 + w) * NR4W + i) * 64 + l] // the 4x4x1 image: see k_pack_U
+                    : Ubwd[((size_t)kb * nr4 + w * NR4W + i) * 64 + l];
     const __amdgpu_buffer_rsrc_t rDG = BF16 ? make_rsrc(DGb, (size_t)S * G4 * B * sizeof(unsigned short))
                                             : make_rsrc(DG, (size_t)S * G4 * B * sizeof(float));
     float dcn = 0.0f; // dcnext, R/lstm.cc:217
@@ -1052,7 +1054,49 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
         BSTAMP_AT(1)
 
         float dhn = 0.0f;
-        if (has_next) {
+        if (M4 && has_next) {
+            // 8-column groups on v_mfma_f32_4x4x1 (16 independent 4x4 outer products per instruction) instead of half-empty
+            // 16x16x4 tiles: block = 8x + 4y + z (lane = 4*block + i) computes, for gate-row k(y),
+            //   D[i][j] += dg[k][column 4x+i] * U^T[unit 4z+j][k]
+            // CBSZ = 2 / ABID = z' makes the four z-blocks of a group read their dg from block z' of the loaded register,
+            // BLGP = 1 / 2 makes both x-halves read the weights from lanes 0-31 / 32-63 of the weight register: one
+            // loaded dg register feeds four instructions, one weight register two, and no lane carries padding
+            // (semantics checked on gfx950 by tools/probes/mfma4x4_probe.hip).  Per wave: NR4W/2 16-byte loads with all
+            // lanes active (half the instructions of the tile form) and 8*NR4W MFMAs of 8 cycles (half the pipe time).
+            constexpr int NL = NR4W / 2, Kw = 16 * NR4W;
+            const int lx = l >> 5, ly = (l >> 4) & 1, lz = (l >> 2) & 3, li = l & 3;
+            const int col4 = COLS * g + 4 * lx + li, col4c = col4 < B ? col4 : B - 1;
+            const int off = (int)((((size_t)(t + 1) * B + col4c) * G4 + Kw * w + 4 * (2 * lz + ly)) * sizeof(float));
+            constexpr int PF = BWD_PF < NL ? BWD_PF : NL;
+            float4 b[NL];
+#pragma unroll
+            for (int i = 0; i < PF; i++) b[i] = ld_sc1(rDG, off + 128 * i);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+#define M4_STEP(av, wq, blgp)                                                          \
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.x, c0, 2, 0, blgp);                 \
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.y, c1, 2, 1, blgp);                 \
+    c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.z, c2, 2, 2, blgp);                 \
+    c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.w, c3, 2, 3, blgp);
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                if (i + PF < NL) b[i + PF] = ld_sc1(rDG, off + 128 * (i + PF));
+                M4_STEP(b[i].x, a[2 * i], 1)
+                M4_STEP(b[i].y, a[2 * i], 2)
+                M4_STEP(b[i].z, a[2 * i + 1], 1)
+                M4_STEP(b[i].w, a[2 * i + 1], 2)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef M4_STEP
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float v = (c0[r] + c1[r]) + (c2[r] + c3[r]);
+                // the two k-parities y sit 16 lanes apart: fold them (ds_swizzle-free: one bpermute per register)
+                red[(w * 4 + r) * 64 + l] = v + __shfl_xor(v, 16, 64);
+            }
+            __syncthreads();
+            BSTAMP_AT(2)
+        } else if (has_next) {
             // Software pipeline with PF fragment loads in flight ahead of the MFMAs.  Left to itself the
             // scheduler keeps only two in flight (a fabric round trip per pair of loads: measured +220
             // cycles per load), and all of them at once measured slower still; sched_barriers pin the order.
@@ -1100,7 +1144,8 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
             if (FUSE) dhy = dhyb[cur][cc * 16 + jj]; // written by the followers one step ago (before barrier A)
             if (has_next) {
                 // D[row = 4*(lane>>4) + reg][col = lane&15]  ->  unit jj lives in lane (jj>>2)*16 + cc, reg jj&3
-                const int src = (jj >> 2) * 16 + cc, reg = jj & 3;
+                // M4: D[reg = column & 3][lane = 32*(column >> 2) + unit]
+                const int src = M4 ? 32 * (cc >> 2) + jj : (jj >> 2) * 16 + cc, reg = M4 ? (cc & 3) : (jj & 3);
 #pragma unroll
                 for (int ww = 0; ww < 8; ww++) dhn += red[(ww * 4 + reg) * 64 + src];
             }
@@ -1341,6 +1386,12 @@ void fwd_persistent_granules(const float4 *Ufwd, const float *W, const float *bi
     }
 }
 
+// the 4x4x1 form of the backward recurrence: fp32, 8-column groups, N a multiple of 64; LSTM_HIP_BWD_M4=0 keeps the
+// half-empty 16x16x4 tiles (A/B switch)
+bool bwd_uses_m4(int N, int cols, bool bf16) {
+    static const int on = getenv("LSTM_HIP_BWD_M4") ? atoi(getenv("LSTM_HIP_BWD_M4")) : 1;
+    return on != 0 && cols == 8 && !bf16 && N % 64 == 0 && N <= 1024;
+}
 // 8-column groups when that still fits one workgroup per CU (more CUs pulling fewer bytes each)
 int bwd_group_cols(int N, int B, int n_cus) {
     static const int force = getenv("LSTM_HIP_BWD_COLS") ? atoi(getenv("LSTM_HIP_BWD_COLS")) : 0;
@@ -1408,6 +1459,32 @@ void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float
     static const int stagger = getenv("LSTM_HIP_BWD_STAGGER") ? atoi(getenv("LSTM_HIP_BWD_STAGGER")) : 0;
     const bool fuse = gpart != nullptr;
     const size_t lds = fuse ? 257 * 64 * sizeof(float) : 0;
+    if (bwd_uses_m4(N, cols, false)) { // Ubwd is the 4x4x1 image here (the caller packs it when bwd_uses_m4 says so)
+#define BWD_LAUNCH4(k, f, s)                                                                                          \
+    do {                                                                                                              \
+        if (f) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persistent<k, 8, f, s, false, true>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 257 * 64 * sizeof(float));      \
+        hipLaunchKernelGGL((k_bwd_persistent<k, 8, f, s, false, true>), grid, block, lds, st, Ubwd, DG, DHy, G, C, H, xi, gpart, \
+                           Why, dY, cnt, abortp, epoch, S, B, stagger, stamps);                                             \
+    } while (0)
+        if (stamps != nullptr && N == 512) {
+            if (fuse) BWD_LAUNCH4(16, true, true);
+            else BWD_LAUNCH4(16, false, true);
+            return;
+        }
+        stamps = nullptr;
+        switch (N / 32) {
+#define X(k)                                  \
+    case k:                                   \
+        if (fuse) BWD_LAUNCH4(k, true, false); \
+        else BWD_LAUNCH4(k, false, false);     \
+        break;
+            X(2) X(4) X(8) X(16) X(32)
+#undef X
+        }
+#undef BWD_LAUNCH4
+        return;
+    }
 #define BWD_LAUNCH(k, c, f, s)                                                                                        \
     do {                                                                                                              \
         if (f) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persistent<k, c, f, s>),              \
