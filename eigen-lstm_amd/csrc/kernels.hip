@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, flo
             int r4 = (int)(q % (N / 4)), kb = (int)(q / (N / 4));
             int r = 16 * r4 + 4 * (l >> 4);
             int k = 16 * kb + (l & 15);
-            Ubwd[e2] = *reinterpret_cast<const float4 *>(U + (size_t)k * G4 + r);
+            if (Ubwd != nullptr) Ubwd[e2] = *reinterpret_cast<const float4 *>(U + (size_t)k * G4 + r);
         }
     }
 }
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const fl
             const size_t e = i - u_off4;        // float4 index inside U: rows 4*(e % N) .. +3 of column e / N
             const int r = 4 * (int)(e % N), k = (int)(e / N);
             // Ubwd[kb][r4][l] = U[16*r4 + 4*(l>>4) + 0..3][16*kb + (l&15)]
-            Ubwd[((size_t)(k >> 4) * (N / 4) + (r >> 4)) * 64 + (((r & 15) >> 2) << 4) + (k & 15)] = p;
+            if (Ubwd != nullptr) Ubwd[((size_t)(k >> 4) * (N / 4) + (r >> 4)) * 64 + (((r & 15) >> 2) << 4) + (k & 15)] = p;
             if (Ubwd4 != nullptr) {
                 float *u4 = reinterpret_cast<float *>(Ubwd4);
                 u4[ubwd4_index(r + 0, k, N)] = p.x;

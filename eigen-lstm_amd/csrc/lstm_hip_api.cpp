@@ -263,7 +263,7 @@ int do_forward(lstm_hip_ctx *h) {
     const int N = h->cfg.N, B = h->cfg.B, S = h->cfg.S, G4 = 4 * N;
     const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
     if (!h->packed) {
-        RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd, h->Ubwd, N, h->st, h->Ubwd4));
+        RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd, h->Ubwd4 ? nullptr : h->Ubwd, N, h->st, h->Ubwd4)); // one backward image is live
         h->packed = true;
     }
     h->n_dby_parts = softmax_parts(h->T);
@@ -409,7 +409,7 @@ int do_allreduce(lstm_hip_ctx *h) {
 }
 
 int do_adagrad(lstm_hip_ctx *h, double lr) {
-    RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd, h->Ubwd, h->st, h->Ubwd4));
+    RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd, h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4));
     h->packed = true; // the U images were refreshed by the same launch
     h->packed16 = false;
     return 0;
