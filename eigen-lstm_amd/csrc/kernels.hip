@@ -305,17 +305,21 @@ void bwd_step(const float4 *Ubwd, const float *DGnext, const float *DHy_t, const
 // row index) so the accumulator holds C^T fragments: lanes then run along m, which is contiguous in
 // column-major C, and the epilogue stores are coalesced.
 // ------------------------------------------------------------------------------------------------
-constexpr int GBK = 16; // k-tile depth; tile = (64*MW) x (64*NI) with 2*MW waves of 64 x (32*NI)
+#ifndef GEMM_BK
+#define GEMM_BK 16
+#endif
+constexpr int GBK = GEMM_BK; // k-tile depth (16; 32 measured the same to slightly slower on dU: 141 vs 144 us); tile = (64*MW) x (64*NI) with 2*MW waves of 64 x (32*NI)
 
 // Tile loaders.  ROWS = tile rows (m or n), NT = threads.  TRANS=false: the source is [rows contiguous] x K
 // (a float4 is 4 consecutive rows of one k); TRANS=true: the source is K-contiguous (a float4 is 4
 // consecutive k of one row).  The LDS image is always [k][row] with row stride ROWS+4.
 template <bool TRANS, int ROWS, int NT> struct GemmTile {
     static constexpr int LD = ROWS + 4;
-    static constexpr int REPS = TRANS ? (ROWS * 4 + NT - 1) / NT : (GBK * (ROWS / 4) + NT - 1) / NT;
-    static_assert(REPS >= 1 && REPS <= 2, "tile / thread-count combination not supported");
+    static constexpr int K4 = GBK / 4; // float4 along k per row (TRANS)
+    static constexpr int REPS = TRANS ? (ROWS * K4 + NT - 1) / NT : (GBK * (ROWS / 4) + NT - 1) / NT;
+    static_assert(REPS >= 1 && REPS <= 4, "tile / thread-count combination not supported");
     __device__ static __forceinline__ void load(const float *__restrict__ src, int ld, int r0, int rmax, int k0, int kend,
-                                                int tid, float4 (&reg)[2]) {
+                                                int tid, float4 (&reg)[4]) {
 #pragma unroll
         for (int q = 0; q < REPS; q++) {
             float4 v = {0.f, 0.f, 0.f, 0.f};
@@ -332,8 +336,8 @@ template <bool TRANS, int ROWS, int NT> struct GemmTile {
                     }
                 }
             } else {
-                constexpr int RSTEP = NT / 4;
-                const int k = k0 + (tid & 3) * 4, rr = (tid >> 2) + q * RSTEP, r = r0 + rr;
+                constexpr int RSTEP = NT / K4;
+                const int k = k0 + (tid % K4) * 4, rr = tid / K4 + q * RSTEP, r = r0 + rr;
                 if (r < rmax && rr < ROWS) {
                     const float *p = src + (size_t)r * ld + k;
                     if (k + 3 < kend) v = *reinterpret_cast<const float4 *>(p);
@@ -347,7 +351,7 @@ template <bool TRANS, int ROWS, int NT> struct GemmTile {
             reg[q] = v;
         }
     }
-    __device__ static __forceinline__ void store(float *lds, int tid, const float4 (&reg)[2]) {
+    __device__ static __forceinline__ void store(float *lds, int tid, const float4 (&reg)[4]) {
 #pragma unroll
         for (int q = 0; q < REPS; q++) {
             if (!TRANS) {
@@ -355,8 +359,8 @@ template <bool TRANS, int ROWS, int NT> struct GemmTile {
                 const int r = (tid % R4) * 4, k = tid / R4 + q * KSTEP;
                 if (k < GBK) *reinterpret_cast<float4 *>(lds + k * LD + r) = reg[q];
             } else {
-                constexpr int RSTEP = NT / 4;
-                const int k = (tid & 3) * 4, r = (tid >> 2) + q * RSTEP;
+                constexpr int RSTEP = NT / K4;
+                const int k = (tid % K4) * 4, r = tid / K4 + q * RSTEP;
                 if (r < ROWS) {
                     lds[(k + 0) * LD + r] = reg[q].x;
                     lds[(k + 1) * LD + r] = reg[q].y;
@@ -378,8 +382,9 @@ __global__ __launch_bounds__(128 * MW) void k_gemm(int M, int Nn, int K, const f
     using TileA = GemmTile<TA, BM, NT>;
     using TileB = GemmTile<!TB, GBN, NT>;
     // two LDS stages: tile k+1 is written while tile k is being read, one barrier per k-tile
-    __shared__ __attribute__((aligned(16))) float As[2][GBK * TileA::LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GBK * TileB::LD];
+    extern __shared__ __attribute__((aligned(16))) float gemm_lds[]; // As[2][GBK*LDA] | Bs[2][GBK*LDB] (up to 100 KB)
+    float(*As)[GBK * TileA::LD] = reinterpret_cast<float(*)[GBK * TileA::LD]>(gemm_lds);
+    float(*Bs)[GBK * TileB::LD] = reinterpret_cast<float(*)[GBK * TileB::LD]>(gemm_lds + 2 * GBK * TileA::LD);
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int wm = w % MW, wn = w / MW;
     // XCD-aware block order (speed only): consecutive block ids are dealt round-robin over the 8 XCDs, each
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(128 * MW) void k_gemm(int M, int Nn, int K, const f
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
 
-    float4 ra[2], rb[2];
+    float4 ra[4], rb[4];
     // op(A): TA=false -> A is M x K, m contiguous (direct); TA=true -> A stored K x M, k contiguous
     // op(B): TB=true  -> B stored Nn x K, n contiguous (direct); TB=false -> B is K x Nn, k contiguous
     TileA::load(A, lda, m0, M, kbeg, kend, tid, ra);
@@ -507,8 +512,14 @@ static void gemm_launch(bool TA, bool TB, int M, int Nn, int K, const float *A, 
                         float *out, int ldo, int kchunk, size_t stride, int z0, int nz, hipStream_t st) {
     const GemmShape sh = gemm_pick_shape(M, Nn, K);
     dim3 grid((M + sh.bm - 1) / sh.bm, (Nn + sh.bn - 1) / sh.bn, nz);
-#define GEMM_LAUNCH(ta, tb, ni, mw) \
-    hipLaunchKernelGGL((k_gemm<ta, tb, ni, mw>), grid, dim3(128 * mw), 0, st, M, Nn, K, A, lda, B, ldb, out, ldo, kchunk, stride, z0)
+#define GEMM_LAUNCH(ta, tb, ni, mw)                                                                                    \
+    do {                                                                                                               \
+        const size_t lds = sizeof(float) * 2 * GBK * ((64 * mw + 4) + (64 * ni + 4));                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm<ta, tb, ni, mw>),                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        hipLaunchKernelGGL((k_gemm<ta, tb, ni, mw>), grid, dim3(128 * mw), lds, st, M, Nn, K, A, lda, B, ldb, out, ldo, \
+                           kchunk, stride, z0);                                                                        \
+    } while (0)
 #define GEMM_NI(ta, tb)                                  \
     do {                                                 \
         if (sh.bm == 256) GEMM_LAUNCH(ta, tb, 2, 4);     \
