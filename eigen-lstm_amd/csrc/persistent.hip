@@ -838,10 +838,11 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_g(const float4 *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward recurrence, t = S-1..1, N = 32*NR4W.  grid (N/16, ceil(B/16)), 512 threads.
-// Workgroup (kb, g) owns hidden units 16kb..16kb+15 for column group g: one 16x16 tile of
-// dhnext = U^T * dg[t+1] (R/lstm.cc:255) with K = 4N split over its 8 waves (U^T A-fragments in
-// VGPRs), then one thread per (unit, column) does R/lstm.cc:228-247,256 and dg[t] is published.
+// backward recurrence, t = S-1..1, N = 32*NR4W.  grid (N/16, ceil(B/COLS)), 512 threads.
+// Workgroup (kb, g) owns hidden units 16kb..16kb+15 for column group g (COLS = 8 or 16 batch columns): the tile
+// dhnext = U^T * dg[t+1] (R/lstm.cc:255) with K = 4N split over its 8 waves (U^T fragments in VGPRs) -- 16x16x4 MFMA
+// tiles, or for 8-column fp32 groups (M4) v_mfma_f32_4x4x1 blocks with operand broadcast, which leave no tile column
+// empty -- then one thread per (unit, column) does R/lstm.cc:228-247,256 and dg[t] is published.
 // ------------------------------------------------------------------------------------------------
 #define BSTAMP_AT(k)                                                                     \
     if (STAMP && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
@@ -851,8 +852,9 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_g(const float4 *__restri
 //                                                          has no part in the elementwise / publish phase
 //   db[rows]    += dg_t[rows, col]                         registers of the elementwise threads
 // The dW update for step t+1 runs during step t (dg is double-buffered in LDS), after the step's second
-// workgroup barrier; the elementwise waves synchronise among themselves through an LDS counter from
-// there on, so the updater never holds up the store / drain / signal / poll path.
+// workgroup barrier; from there on the elementwise waves do not synchronise with anything (each transposes its own
+// gates by DPP, stores, drains and arrives on the counter for itself), so neither the updater nor the followers hold
+// up the store / drain / signal / poll path.
 //   DHy_t = Why^T*dy_t (R/lstm.cc:228) for this workgroup's 16 units, one step ahead of its use, and
 //   dWhy[:, units] += dy_t * h_t[units]^T (R/lstm.cc:226)    four "follower" waves (4..7), 24 MFMAs a step
 // Each column group g leaves one partial block [dW | (dU, unused) | db | dWhy] (the layout of the flat
@@ -935,7 +937,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     if (!STAMP)
         for (int i = 0; i < g * (stagger & 255); i++) __builtin_amdgcn_s_sleep(32); // see k_fwd_persistent
 
-    // sync point of the EW elementwise waves only (LDS counter; LDS operations of a wave complete in order)
     // dW[:, x] += dg[:, col] (R/lstm.cc:251) for the step whose dg sits in stage[par]: wave EW, one thread per
     // row, walking the columns in order (deterministic); tu is that step
     auto update = [&](int par, int tu) {
