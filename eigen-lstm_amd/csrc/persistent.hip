@@ -61,6 +61,12 @@ template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
 }
 
 // fragment loads kept in flight ahead of the MFMAs (see the pipelines below); -D overrides for A/B builds
+#ifndef XCD_LOCAL
+#define XCD_LOCAL 1 // backward recurrence: plain-store hand-off when a column group is verified to sit on one XCD
+#endif
+#ifndef XCD_FORCE_LOCAL
+#define XCD_FORCE_LOCAL 0 // test builds only: skip the verification (wrong results when groups span XCDs)
+#endif
 #ifndef BWD_PF
 #define BWD_PF 6
 #endif
@@ -885,6 +891,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     __shared__ float olred[4 * 4 * 64];
     __shared__ float dhyb[2][16 * 16];
     __shared__ unsigned s_ol;
+    __shared__ int s_local;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int NBK = gridDim.x, NG = gridDim.y;
     const int lin_ = blockIdx.x + NBK * blockIdx.y;
@@ -914,8 +921,20 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     if (tid == 0) {
         s_abort = 0;
         s_ol = 0;
+        s_local = 0;
     }
+    // XCD-local hand-off (speed only, checked every launch): when all workgroups of this column group run on ONE XCD, dg
+    // can be published with plain stores -- the lines stay in that XCD's L2, which serves the group's sc1 loads directly
+    // (406 -> 391 us) -- instead of sc1 write-through stores that every consumer pulls back over the fabric.  Placement is
+    // observed, not promised, so each workgroup publishes its HW_REG_XCC_ID (sc1, before its first arrival) in the unused
+    // step-0 counter slots of its group; after the first wait every workgroup of the group reads the same NBK words
+    // and takes the plain-store path only if they all agree.  The first publish is always sc1.
+    unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE; // step index 0 is never a hand-off step (t = 1..S-1)
+    if (XCD_LOCAL && !BF16 && tid == 0)
+        __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT); // getreg(id 20 = XCC_ID, offset 0, size 4)
     unsigned ol_target = 0;
+    bool local_pub = false;
     // Why^T A-fragments of the follower waves: wave ow = w-4 takes output rows m in [64*ow, 64*ow+64);
     // fragment i of k-step ks4 is Why[m = 64*ow + 16*ks4 + 4*(l>>4) + i][16*kb + (l&15)]
     float4 wa[FUSE ? 4 : 1];
@@ -1049,9 +1068,23 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
         if (has_next && w == 0) {
             const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
             if (!wait_arrivals<BWD_SH>(cpn, NBK, epoch * EW, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
+            if (XCD_LOCAL && !BF16 && t == S - 2) { // every workgroup of the group has published its XCC id by now
+                bool same = true;
+                unsigned mine = 0;
+                for (int i = l; i < NBK; i += 64) {
+                    const unsigned v = __hip_atomic_load(xcc_tab + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mine = v;
+                    same = same && (v >> 4) == epoch; // written in this launch
+                }
+                const unsigned first = __builtin_amdgcn_readfirstlane(mine);
+                for (int i = l; i < NBK; i += 64) same = same && mine == first;
+                if (NBK > 64) same = false; // one load per lane covers the grids in use; larger ones keep the sc1 path
+                if ((XCD_FORCE_LOCAL || __all(same)) && l == 0) s_local = 1;
+            }
         }
         __syncthreads();
         if (s_abort) return;
+        if (XCD_LOCAL && !BF16 && t == S - 2) local_pub = s_local != 0; // decided by wave 0 just above; kept in a register
         BSTAMP_AT(1)
 
         float dhn = 0.0f;
@@ -1206,7 +1239,10 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                             pack_bf16x8(v, v2), rDG,
                             (int)((((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) * sizeof(unsigned short)), 0, 16);
                 } else {
-                    st_sc1(v, rDG, (int)((((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) * sizeof(float)));
+                    if (XCD_LOCAL && local_pub)
+                        *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
+                    else
+                        st_sc1(v, rDG, (int)((((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) * sizeof(float)));
                 }
             }
             if (t > 1) {
