@@ -895,7 +895,10 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int NBK = gridDim.x, NG = gridDim.y;
     const int lin_ = blockIdx.x + NBK * blockIdx.y;
-    const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
+    // bit 30 of `stagger` (LSTM_HIP_BWD_SPREAD=1, tests): keep the dispatch-order mapping, which spreads every column
+    // group over all XCDs -- the placement the XCD-local hand-off below must detect and decline
+    const bool remap = GROUP_REMAP && !(stagger & (1 << 30));
+    const int kb = remap ? lin_ / NG : (int)blockIdx.x, g = remap ? lin_ % NG : (int)blockIdx.y;
     const int q = l >> 4;
     // COLS = 16: the MFMA tile is full.  COLS = 8: lanes 8..15 of the B operand are never used (their tile
     // columns are discarded) -- the matrix pipe is not what bounds a step, and 8-column groups put
@@ -1067,7 +1070,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
         if (FUSE && w >= 4 && t >= 2) output_layer_fetch(t - 1);
         if (has_next && w == 0) {
             const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
-            if (!wait_arrivals<BWD_SH>(cpn, NBK, epoch * EW, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
+            if (!wait_arrivals<BWD_SH>(cpn, NBK, epoch * EW, abortp, l, (stagger >> 8) & 0xffff) && l == 0) s_abort = 1;
             if (XCD_LOCAL && !BF16 && t == S - 2) { // every workgroup of the group has published its XCC id by now
                 bool same = true;
                 unsigned mine = 0;
@@ -1493,7 +1496,8 @@ void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float
         }
         return;
     }
-    static const int stagger = getenv("LSTM_HIP_BWD_STAGGER") ? atoi(getenv("LSTM_HIP_BWD_STAGGER")) : 0;
+    static const int stagger = (getenv("LSTM_HIP_BWD_STAGGER") ? atoi(getenv("LSTM_HIP_BWD_STAGGER")) & 0xffffff : 0) |
+                               (getenv("LSTM_HIP_BWD_SPREAD") && atoi(getenv("LSTM_HIP_BWD_SPREAD")) ? (1 << 30) : 0);
     const bool fuse = gpart != nullptr;
     const size_t lds = fuse ? 257 * 64 * sizeof(float) : 0;
     if (bwd_uses_m4(N, cols, false)) { // Ubwd is the 4x4x1 image here (the caller packs it when bwd_uses_m4 says so)

@@ -7,6 +7,8 @@ in libm vs ocml exp/tanh/log2 -- the reference itself leaves the order to Eigen/
   gradients, per tensor           : |d| <= 2e-4 * max|ref|
   post-Adagrad params, per tensor : |d| <= 2e-4 * lr   (one step moves a weight by at most ~lr)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -14,6 +16,7 @@ import gpu_util as gu
 from oracle_lib import split_params
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 ACT_TOL, LOSS_TOL, GRAD_TOL = 2e-5, 2e-5, 2e-4
 
@@ -517,3 +520,33 @@ def test_last_step_loss_mode(oracle32):
     assert abs(bits_all - fw["loss_bits"]) <= LOSS_TOL * (S - 1)
     assert abs(got - want) <= LOSS_TOL
     assert np.array_equal(g0, g1)
+
+
+def test_backward_declines_xcd_local_handoff_when_groups_span_xcds(tmp_path):
+    """The backward recurrence publishes dg with plain stores only after checking (HW_REG_XCC_ID) that a column group's
+    workgroups share an XCD.  LSTM_HIP_BWD_SPREAD=1 keeps the dispatch-order mapping, which puts every group on all eight
+    XCDs: the check must then keep the sc1 path and the results must not change.  (With the check compiled out,
+    -DXCD_FORCE_LOCAL=1, this placement gives wrong gradients: DESIGN.md.)"""
+    import subprocess
+    import sys
+    script = tmp_path / "spread.py"
+    script.write_text(
+        "import sys, os\n"
+        f"sys.path[:0] = [{os.path.dirname(os.path.abspath(__file__))!r}, {os.path.join(ROOT, 'eigen-lstm_amd')!r}]\n"
+        "import numpy as np, gpu_util as gu, lstm_hip\n"
+        "from oracle_lib import Oracle\n"
+        "o = Oracle('f32')\n"
+        "N, S, B = 256, 12, 64\n"
+        "P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=91)\n"
+        "fw = o.forward(N, 256, S, B, P, xi, ti, h0, c0)\n"
+        "dref = o.backward(N, 256, S, B, P, xi, ti, fw)\n"
+        "L = lstm_hip.Lstm(N, S, B)\n"
+        "L.set_params(P); L.set_state(0, h0, c0); L.set_window(xi, ti); L.forward(); L.backward()\n"
+        "rep = gu.grads_report(L.get_grads(), dref, N)\n"
+        "L.close()\n"
+        "print('MAXREL', max(rep.values()))\n")
+    env = dict(os.environ, LSTM_HIP_BWD_SPREAD="1")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    worst = float(out.stdout.strip().split("MAXREL")[-1])
+    assert worst <= GRAD_TOL, out.stdout
