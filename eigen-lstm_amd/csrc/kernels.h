@@ -24,7 +24,11 @@ struct ParamLayout {
 // ---- recurrent weight repack (once per window, after Adagrad) -------------------------------
 // Ufwd[N/4][N/16][64] float4 : MFMA 16x16x4 A-fragments of U for the forward product
 // Ubwd[N/16][N/4][64] float4 : A-fragments of U^T for the backward product
-void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, float4 *Ubwd4 = nullptr);
+void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, float4 *Ubwd4 = nullptr,
+            float4 *Ufwd4 = nullptr);
+bool fwd_uses_third_form(int N, int B, int n_cus); // forward recurrence on 8-column groups (k_fwd_persistent3)
+void fwd_persistent3(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
+                     unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B, bool fast, hipStream_t st);
 bool bwd_uses_m4(int N, int cols, bool bf16); // backward recurrence on v_mfma_f32_4x4x1 (8-column groups, fp32)
 
 // ---- baseline engine: one launch per timestep -----------------------------------------------
@@ -109,7 +113,7 @@ void dW_sums(const float *DG, int T, int G4, float *dW, float *db, void *scratch
 // ---- Adagrad over the flat block (R/lstm.cc:261-272; eps added in double, :25,46-48)
 // When Ufwd/Ubwd are given, the U block also refreshes both MFMA fragment images (fused pack_U).
 void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
-             hipStream_t st, float4 *Ubwd4 = nullptr);
+             hipStream_t st, float4 *Ubwd4 = nullptr, float4 *Ufwd4 = nullptr);
 
 // ---- window builder on the device (OV/lstm_eigen_opt/lstm.cc:190-213): x/target rings + flat copies,
 //      cursor advance, and the h/c carry (column 1 -> column 0).  Single workgroup.

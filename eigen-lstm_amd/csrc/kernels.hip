@@ -53,21 +53,40 @@ __device__ __forceinline__ size_t ubwd4_index(int gk, int hr, int N) { // float 
     const int l = 32 * xp + 16 * y + (hr & 15);
     return ((((size_t)(hr >> 4) * 8 + w) * (N / 32) + m) * 64 + l) * 4 + zp;
 }
+//   Ufwd4[kb][w][pass][L][eh][sh][l].c (optional; third form of the forward recurrence, k_fwd_persistent3): wave w of
+//        workgroup kb owns input indices [Kw*w, Kw*(w+1)), Kw = N/8; lane l = 32x' + 4u + j; slot s = 4*sh + c;
+//        = U[gate j of unit 16*kb + 8*pass + u][Kw*w + 32*L + 4*s + 2*eh + x']
+__device__ __forceinline__ size_t ufwd4_index(int row, int k, int N) { // float index of U[row][k] in Ufwd4
+    const int gate = row / N, u = row % N, Kw = N / 8, w = k / Kw, kk = k % Kw, rem = kk & 31;
+    const int L = kk >> 5, s = rem >> 2, eh = (rem >> 1) & 1, xp = rem & 1;
+    const int l = 32 * xp + 4 * (u & 7) + gate;
+    return (((((((size_t)(u >> 4) * 8 + w) * 2 + ((u >> 3) & 1)) * (Kw / 32) + L) * 2 + eh) * 2 + (s >> 2)) * 64 + l) * 4 + (s & 3);
+}
 __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, float4 *__restrict__ Ufwd,
-                                                float4 *__restrict__ Ubwd, float4 *__restrict__ Ubwd4, int N) {
+                                                float4 *__restrict__ Ubwd, float4 *__restrict__ Ubwd4,
+                                                float4 *__restrict__ Ufwd4, int N) {
     const int G4 = 4 * N;
     const size_t nf4 = (size_t)N * N; // float4 count of each image (4N*N floats)
-    const size_t total = (Ubwd4 ? 3 : 2) * nf4;
+    const size_t total = ((Ubwd4 || Ufwd4) ? 3 : 2) * nf4;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         if (e >= 2 * nf4) { // one float4 of U (4 gate rows of one hidden column) -> four scalars of Ubwd4
             const size_t e3 = e - 2 * nf4;
             const int r = 4 * (int)(e3 % N), k = (int)(e3 / N);
             const float4 p = *reinterpret_cast<const float4 *>(U + (size_t)k * G4 + r);
             float *u4 = reinterpret_cast<float *>(Ubwd4);
-            u4[ubwd4_index(r + 0, k, N)] = p.x;
-            u4[ubwd4_index(r + 1, k, N)] = p.y;
-            u4[ubwd4_index(r + 2, k, N)] = p.z;
-            u4[ubwd4_index(r + 3, k, N)] = p.w;
+            if (Ubwd4 != nullptr) {
+                u4[ubwd4_index(r + 0, k, N)] = p.x;
+                u4[ubwd4_index(r + 1, k, N)] = p.y;
+                u4[ubwd4_index(r + 2, k, N)] = p.z;
+                u4[ubwd4_index(r + 3, k, N)] = p.w;
+            }
+            if (Ufwd4 != nullptr) {
+                float *f4 = reinterpret_cast<float *>(Ufwd4);
+                f4[ufwd4_index(r + 0, k, N)] = p.x;
+                f4[ufwd4_index(r + 1, k, N)] = p.y;
+                f4[ufwd4_index(r + 2, k, N)] = p.z;
+                f4[ufwd4_index(r + 3, k, N)] = p.w;
+            }
         } else if (e < nf4) {
             int l = (int)(e & 63);
             size_t q = e >> 6;
@@ -79,7 +98,7 @@ __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, flo
             v.y = U[(size_t)(k + 1) * G4 + row];
             v.z = U[(size_t)(k + 2) * G4 + row];
             v.w = U[(size_t)(k + 3) * G4 + row];
-            Ufwd[e] = v;
+            if (Ufwd != nullptr) Ufwd[e] = v;
         } else {
             size_t e2 = e - nf4;
             int l = (int)(e2 & 63);
@@ -91,11 +110,11 @@ __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, flo
         }
     }
 }
-void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, float4 *Ubwd4) {
-    size_t n = (Ubwd4 ? 3 : 2) * (size_t)N * N;
+void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, float4 *Ubwd4, float4 *Ufwd4) {
+    size_t n = ((Ubwd4 || Ufwd4) ? 3 : 2) * (size_t)N * N;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_pack_U, dim3(blocks), dim3(256), 0, st, U, Ufwd, Ubwd, Ubwd4, N);
+    hipLaunchKernelGGL(k_pack_U, dim3(blocks), dim3(256), 0, st, U, Ufwd, Ubwd, Ubwd4, Ufwd4, N);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -985,7 +1004,7 @@ __device__ __forceinline__ float adagrad1(float p, float d, float &m, float lr) 
 __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const float *__restrict__ dP,
                                                  float *__restrict__ mem, size_t n4, float lr, size_t u_off4, int N,
                                                  float4 *__restrict__ Ufwd, float4 *__restrict__ Ubwd,
-                                                 float4 *__restrict__ Ubwd4) {
+                                                 float4 *__restrict__ Ubwd4, float4 *__restrict__ Ufwd4) {
     const size_t u_n4 = (size_t)N * N; // float4 count of U
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 p = reinterpret_cast<float4 *>(P)[i];
@@ -997,7 +1016,7 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const fl
         p.w = adagrad1(p.w, d.w, m.w, lr);
         reinterpret_cast<float4 *>(P)[i] = p;
         reinterpret_cast<float4 *>(mem)[i] = m;
-        if (Ufwd != nullptr && i >= u_off4 && i < u_off4 + u_n4) {
+        if ((Ufwd != nullptr || Ufwd4 != nullptr) && i >= u_off4 && i < u_off4 + u_n4) {
             const size_t e = i - u_off4;        // float4 index inside U: rows 4*(e % N) .. +3 of column e / N
             const int r = 4 * (int)(e % N), k = (int)(e / N);
             // Ubwd[kb][r4][l] = U[16*r4 + 4*(l>>4) + 0..3][16*kb + (l&15)]
@@ -1009,6 +1028,14 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const fl
                 u4[ubwd4_index(r + 2, k, N)] = p.z;
                 u4[ubwd4_index(r + 3, k, N)] = p.w;
             }
+            if (Ufwd4 != nullptr) {
+                float *f4 = reinterpret_cast<float *>(Ufwd4);
+                f4[ufwd4_index(r + 0, k, N)] = p.x;
+                f4[ufwd4_index(r + 1, k, N)] = p.y;
+                f4[ufwd4_index(r + 2, k, N)] = p.z;
+                f4[ufwd4_index(r + 3, k, N)] = p.w;
+            }
+            if (Ufwd == nullptr) continue;
             // Ufwd[jb][k4][l].i = U[(l&3)*N + 4*jb + ((l&15)>>2)][16*k4 + 4*(l>>4) + i]
             const int gate = r / N, hid = r % N; // 4 rows share the gate (N % 4 == 0)
             const int k4 = k >> 4, kq = (k & 15) >> 2, ki = k & 3;
@@ -1024,11 +1051,11 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const fl
     }
 }
 void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
-             hipStream_t st, float4 *Ubwd4) {
+             hipStream_t st, float4 *Ubwd4, float4 *Ufwd4) {
     const size_t n4 = n / 4; // the flat block is a multiple of 4 floats (M = 256, N % 16 == 0)
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adagrad, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4);
+    hipLaunchKernelGGL(k_adagrad, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4);
 }
 
 // ------------------------------------------------------------------------------------------------

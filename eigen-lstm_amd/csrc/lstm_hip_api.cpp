@@ -103,6 +103,7 @@ struct lstm_hip_ctx {
     float *P = nullptr, *dP = nullptr, *mem = nullptr;
     float4 *Ufwd = nullptr, *Ubwd = nullptr;
     float4 *Ubwd4 = nullptr; // weight image of the 4x4x1 backward form (kernels.hip, k_pack_U), when bwd_uses_m4
+    float4 *Ufwd4 = nullptr; // ... of the third-form forward kernel, when fwd_uses_third_form
     bool packed = false;
     float *H = nullptr, *C = nullptr, *G = nullptr, *DG = nullptr, *Y = nullptr, *Pr = nullptr, *DHy = nullptr;
     float *dcnext = nullptr, *colloss = nullptr, *dby_part = nullptr, *slabs = nullptr;
@@ -232,6 +233,10 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
                                                    h->cnt, h->abortp, h->fwd_epoch, N, S, B, fast, h->st));
             return 0;
         }
+        if (h->Ufwd4)
+            RUN(K_FWD_PERSIST, fwd_persistent3(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->cnt,
+                                               h->abortp, h->fwd_epoch, N, S, B, fast, h->st));
+        else
         RUN(K_FWD_PERSIST, fwd_persistent(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->cnt,
                                           h->abortp, h->fwd_epoch, N, S, B, fast, h->st, h->stamps));
     } else {
@@ -263,7 +268,8 @@ int do_forward(lstm_hip_ctx *h) {
     const int N = h->cfg.N, B = h->cfg.B, S = h->cfg.S, G4 = 4 * N;
     const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
     if (!h->packed) {
-        RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd, h->Ubwd4 ? nullptr : h->Ubwd, N, h->st, h->Ubwd4)); // one backward image is live
+        RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd4 ? nullptr : h->Ufwd, h->Ubwd4 ? nullptr : h->Ubwd, N, h->st, h->Ubwd4,
+                             h->Ufwd4)); // one image per direction is live
         h->packed = true;
     }
     h->n_dby_parts = softmax_parts(h->T);
@@ -409,7 +415,8 @@ int do_allreduce(lstm_hip_ctx *h) {
 }
 
 int do_adagrad(lstm_hip_ctx *h, double lr) {
-    RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd, h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4));
+    RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
+                           h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4));
     h->packed = true; // the U images were refreshed by the same launch
     h->packed16 = false;
     return 0;
@@ -510,11 +517,15 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
         HIP_TRY(hipMalloc(&h->Ubwd16, (size_t)8 * N * N));
     }
     if (h->persistent && bwd_uses_m4((int)N, h->bwd_cols, h->bf16)) ALLOC(h->Ubwd4, N * N);
+    if (h->persistent && !h->bf16 && !(cfg->flags & (LSTM_HIP_GRANULE_HANDOFF | LSTM_HIP_DEBUG_STAMPS)) &&
+        fwd_uses_third_form((int)N, (int)B, prop.multiProcessorCount))
+        ALLOC(h->Ufwd4, N * N);
     if (h->persistent && !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512) // larger N: the dU tiles no longer fit the VGPRs
         ALLOC(h->gpart, (size_t)((B + h->bwd_cols - 1) / h->bwd_cols) * bwd_partial_floats(cfg->N));
     // followers need whole MFMA k-tiles and whole softmax waves per time chunk
     h->overlap = h->persistent && !(cfg->flags & (LSTM_HIP_NO_OVERLAP | LSTM_HIP_GRANULE_HANDOFF | LSTM_HIP_BF16_RECURRENCE)) && cfg->B % 16 == 0;
     if (const char *e = getenv("LSTM_HIP_OVERLAP_MASK")) h->overlap_mask = atoi(e);
+    if (h->Ufwd4) h->overlap_mask &= ~1; // the forward followers count arrivals per 16-column group
     if (h->overlap && (h->overlap_mask & 4)) {
         // CU-partitioned overlap: the backward recurrence (N/16 * ceil(B/16) workgroups, one per CU) gets the
         // even CUs, its followers the odd ones, so they do not compete for SIMD issue slots or LDS.
@@ -541,7 +552,7 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     (void)hipStreamSynchronize(h->st);
     if (h->st2) (void)hipStreamSynchronize(h->st2);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-    void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->Ubwd4, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
+    void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->Ubwd4, h->Ufwd4, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
                     h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->Hg, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);

@@ -399,6 +399,176 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2(const float4 *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward recurrence, third form: grid (N/16, ceil(B/8)), 512 threads, the counterpart of the backward kernel's 4x4x1
+// form.  A workgroup owns 16 units (64 gate rows) for a group of EIGHT batch columns, so a column group is N/16 = 32
+// workgroups at N = 512: one XCD's worth, which (checked every launch, see k_bwd_persistent) lets h_t be published
+// with plain stores that stay in the XCD's L2.  8-column groups on 16x16x4 tiles would waste half the matrix pipe;
+// v_mfma_f32_4x4x1 with operand broadcast does not: block = 8x + u (lane = 4*block + i, u = 0..7) computes
+//   D[i][j] += h[k][column 4x+i] * U[gate j of unit 8*pass + u][k]                 (pass = 0, 1)
+// CBSZ = 3 / ABID = s makes all eight u-blocks of a half read h from slot s of the loaded register (one register = 8
+// values of k x 8 columns = 8 instructions), BLGP = 1 / 2 makes both x-halves read the weights from one half of the
+// weight register (2 values of k each).  Every lane carries data and no partial sums need folding across lanes.  K is
+// split over the 8 waves; waves 0 and 1 finish the 128 (unit, column) pairs.  N = 256*NKQ, weights Ufwd4 (k_pack_U).
+// ------------------------------------------------------------------------------------------------
+template <int NKQ, bool FAST>
+__global__ __launch_bounds__(512) void k_fwd_persistent3(const float4 *__restrict__ Ufwd4, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, float *H, float *__restrict__ C,
+                                                         float *__restrict__ G, const int32_t *__restrict__ xi,
+                                                         unsigned *cnt, unsigned *abortp, unsigned epoch, int S, int B) {
+    constexpr int N = 256 * NKQ, G4 = 4 * N, Kw = N / 8, NL = Kw / 32, RS = 136;
+    __shared__ float red[8 * 4 * RS]; // [wave][gate][column*16 + unit], rows padded (bank spread of the writes)
+    __shared__ int s_abort, s_local;
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int NB3 = gridDim.x, NG = gridDim.y;
+    const int lin_ = blockIdx.x + NB3 * blockIdx.y;
+    const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
+    // MFMA role: lane = 32x + 4u + i
+    const int lx = l >> 5, lu = (l >> 2) & 7, li = l & 3;
+    const int mcol = 8 * g + 4 * lx + li, mcolc = mcol < B ? mcol : B - 1;
+    // gating role (waves 0, 1): tid = column*16 + unit
+    const int gc = (tid >> 4) & 7, gu = tid & 15;
+    const int col = 8 * g + gc, colc = col < B ? col : B - 1;
+    const int j = 16 * kb + gu;
+
+    float4 wq[2][NL][2][2]; // [pass][L][k-pair half][slot half], components: slot & 3
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++)
+#pragma unroll
+        for (int L = 0; L < NL; L++)
+#pragma unroll
+            for (int eh = 0; eh < 2; eh++)
+#pragma unroll
+                for (int sh = 0; sh < 2; sh++)
+                    wq[ps][L][eh][sh] = Ufwd4[(((((((size_t)kb * 8 + w) * 2 + ps) * NL + L) * 2 + eh) * 2 + sh) * 64) + l];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (w < 2) {
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
+        cprev = C[(size_t)colc * N + j];
+    }
+    const __amdgpu_buffer_rsrc_t rH = make_rsrc(H, (size_t)S * N * B * sizeof(float));
+    if (tid == 0) {
+        s_abort = 0;
+        s_local = 0;
+    }
+    // XCD-local hand-off, verified per launch exactly as in k_bwd_persistent (step-0 counter slots of the group)
+    unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
+    if (XCD_LOCAL && tid == 0)
+        __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    bool local_pub = false;
+    __syncthreads();
+
+    for (int t = 1; t < S; t++) {
+        float wx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w < 2) {
+            const int x = xi[t * B + colc];
+            if (x >= 0) {
+#pragma unroll
+                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
+            }
+        }
+        if (w == 0 && t > 1) {
+            const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
+            if (!wait_arrivals<FWD_SH>(cp, 2 * NB3, epoch, abortp, l) && l == 0) s_abort = 1;
+            if (XCD_LOCAL && t == 2) { // every workgroup of the group has published its XCC id by now
+                bool same = true;
+                unsigned mine = 0;
+                for (int i = l; i < NB3; i += 64) {
+                    const unsigned v = __hip_atomic_load(xcc_tab + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mine = v;
+                    same = same && (v >> 4) == epoch;
+                }
+                const unsigned first = __builtin_amdgcn_readfirstlane(mine);
+                for (int i = l; i < NB3; i += 64) same = same && mine == first;
+                if (NB3 > 64) same = false;
+                if ((XCD_FORCE_LOCAL || __all(same)) && l == 0) s_local = 1;
+            }
+        }
+        __syncthreads();
+        if (s_abort) return;
+        if (XCD_LOCAL && t == 2) local_pub = s_local != 0;
+
+        const int off = (int)((((size_t)(t - 1) * B + mcolc) * N + Kw * w + 4 * lu) * sizeof(float));
+        float4 b[NL];
+#pragma unroll
+        for (int i = 0; i < NL; i++) b[i] = ld_sc1(rH, off + 128 * i);
+        // four independent accumulation chains: [pass][slot parity]
+        f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
+#define F3_HALF(av, q0, q1, s0, blgp)                                                   \
+    c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.x, c00, 3, s0 + 0, blgp);          \
+    c10 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.x, c10, 3, s0 + 0, blgp);          \
+    c01 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.y, c01, 3, s0 + 1, blgp);          \
+    c11 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.y, c11, 3, s0 + 1, blgp);          \
+    c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.z, c00, 3, s0 + 2, blgp);          \
+    c10 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.z, c10, 3, s0 + 2, blgp);          \
+    c01 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.w, c01, 3, s0 + 3, blgp);          \
+    c11 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.w, c11, 3, s0 + 3, blgp);
+#define F3_STEP(av, L, eh, blgp)                             \
+    F3_HALF(av, wq[0][L][eh][0], wq[1][L][eh][0], 0, blgp)   \
+    F3_HALF(av, wq[0][L][eh][1], wq[1][L][eh][1], 4, blgp)
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            F3_STEP(b[i].x, i, 0, 1)
+            F3_STEP(b[i].y, i, 0, 2)
+            F3_STEP(b[i].z, i, 1, 1)
+            F3_STEP(b[i].w, i, 1, 2)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef F3_STEP
+#undef F3_HALF
+        // lane (x, u, j), reg r of pass ps holds gate j of unit 8*ps + u for column 4x + r: leave it where the gating
+        // thread (column*16 + unit) reads consecutive addresses
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            red[(w * 4 + li) * RS + (4 * lx + r) * 16 + lu] = c00[r] + c01[r];
+            red[(w * 4 + li) * RS + (4 * lx + r) * 16 + 8 + lu] = c10[r] + c11[r];
+        }
+        __syncthreads();
+
+        if (w < 2) {
+            float pre[4];
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) {
+                float uh = red[(0 * 4 + gt) * RS + tid];
+#pragma unroll
+                for (int ww = 1; ww < 8; ww++) uh += red[(ww * 4 + gt) * RS + tid];
+                pre[gt] = (wx[gt] + uh) + bs[gt]; // R/lstm.cc:176
+            }
+            const float ig = p_sigm<FAST>(pre[0]), og = p_sigm<FAST>(pre[1]), fg = p_sigm<FAST>(pre[2]); // :179
+            const float ug_ = p_tanh<FAST>(pre[3]);                                                       // :182
+            const float cv = p_tanh<FAST>(ig * ug_ + fg * cprev);                                         // :185-189
+            const float hv = og * cv;                                                                     // :192
+            cprev = cv;
+            // four consecutive units sit in the four lanes of a quad: gather them for one 16-byte store
+            float4 h4;
+            h4.x = dpp_f<0x00>(hv); // quad_perm [0,0,0,0]
+            h4.y = dpp_f<0x55>(hv); // [1,1,1,1]
+            h4.z = dpp_f<0xAA>(hv); // [2,2,2,2]
+            h4.w = dpp_f<0xFF>(hv); // [3,3,3,3]
+            if ((gu & 3) == 0 && col < B) {
+                if (XCD_LOCAL && local_pub) *reinterpret_cast<float4 *>(H + ((size_t)t * B + col) * N + j) = h4;
+                else st_sc1(h4, rH, (int)((((size_t)t * B + col) * N + j) * sizeof(float)));
+            }
+            if (t + 1 < S) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (l == 0)
+                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * CNT_SLOTS + ((2 * kb + w) & (FWD_SH - 1))) * CNT_STRIDE, 1u,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (col < B) {
+                float *gcp = G + ((size_t)t * B + col) * G4 + j;
+                gcp[0] = ig;
+                gcp[N] = og;
+                gcp[2 * N] = fg;
+                gcp[3 * N] = ug_;
+                C[((size_t)t * B + col) * N + j] = cv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 recurrence (LSTM_HIP_BF16_RECURRENCE, BASELINE configs[4]): the operands of U*h_prev are bfloat16
 // (round-to-nearest-even of the fp32 master weights and of the published h), the accumulation is fp32,
 // everything else is the fp32 kernel above.  MFMA 16x16x32 bf16: A[row=l&15][k=8*(l>>4)+j],
@@ -1347,11 +1517,28 @@ static bool fwd_second_form(int N) {
     return form != 1 && (N == 128 || N == 256 || N == 512 || N == 1024);
 }
 
+// third form (k_fwd_persistent3): 8-column groups, one workgroup per CU; N = 256, 512, 1024; LSTM_HIP_FWD_FORM=2 / 1 keep
+// the second / first
+bool fwd_uses_third_form(int N, int B, int n_cus) {
+    static const int form = getenv("LSTM_HIP_FWD_FORM") ? atoi(getenv("LSTM_HIP_FWD_FORM")) : 3;
+    return form == 3 && (N == 256 || N == 512 || N == 1024) && B > 8 && (N / 16) * ((B + 7) / 8) <= n_cus;
+}
+
 bool persistent_supported(int N, int B, int n_cus) {
     if (N % 64 != 0 || N > 1024) return false;
-    const int NG = (B + 15) / 16;
+    int NG = (B + 15) / 16;
     int fb = 0, bb = 0, fwd_tiles = N / 4;
-    if (fwd_second_form(N)) {
+    if (fwd_uses_third_form(N, B, n_cus)) {
+        fwd_tiles = N / 16;
+        NG = (B + 7) / 8;
+        switch (N / 256) {
+#define X(k) case k: fb = blocks_per_cu(k_fwd_persistent3<k, false>, 512); break;
+            X(1) X(2) X(4)
+#undef X
+        }
+        if (fb < 1) return false;
+        fb = 1; // the form is chosen only when one workgroup per CU suffices
+    } else if (fwd_second_form(N)) {
         fwd_tiles = N / 8;
         switch (N / 128) {
 #define X(k) case k: fb = blocks_per_cu(k_fwd_persistent2<k, false>, 512); break;
@@ -1375,7 +1562,7 @@ bool persistent_supported(int N, int B, int n_cus) {
     if (fb > 1) fb -= 1;
     if (bb > 1) bb -= 1;
     if (fb > 8) fb = 8;
-    return (size_t)fwd_tiles * NG <= (size_t)fb * n_cus && (size_t)(N / 16) * NG <= (size_t)bb * n_cus;
+    return (size_t)fwd_tiles * NG <= (size_t)fb * n_cus && (size_t)(N / 16) * ((B + 15) / 16) <= (size_t)bb * n_cus;
 }
 
 void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
@@ -1407,6 +1594,20 @@ void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float
         else hipLaunchKernelGGL((k_fwd_persistent<k, false>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B, stagger, nullptr);    \
         break;
         FWD_CASES(X)
+#undef X
+    }
+}
+
+void fwd_persistent3(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
+                     unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B, bool fast, hipStream_t st) {
+    const dim3 grid(N / 16, (B + 7) / 8), block(512);
+    switch (N / 256) {
+#define X(k)                                                                                                          \
+    case k:                                                                                                           \
+        if (fast) hipLaunchKernelGGL((k_fwd_persistent3<k, true>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B); \
+        else hipLaunchKernelGGL((k_fwd_persistent3<k, false>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B);    \
+        break;
+        X(1) X(2) X(4)
 #undef X
     }
 }

@@ -1,6 +1,7 @@
 // Probe: operand/broadcast semantics of v_mfma_f32_4x4x1_16b_f32 with CBSZ/ABID/BLGP on gfx950.
 // Model under test (lane = 4*block + i, block = 8x + 4y + z):
-//   A_block(x,y,z)[i] = a[lane(x, y, abid, i)]          (cbsz = 2: groups of 4 consecutive blocks share block `abid`)
+//   A_block(x,y,z)[i] = a[lane(x, y, abid, i)]          (cbsz = 2: groups of 4 consecutive blocks share block `abid`;
+//                                                         cbsz = 3: groups of 8, abid = 0..7)
 //   B_block(x,y,z)[j] = b[lane(blgp==1 ? 0 : 1, y, z, j)] (blgp = 1: lanes 0-31 -> 32-63; blgp = 2: lanes 32-63 -> 0-31)
 //   D[reg i][lane(block, j)] += A_block[i] * B_block[j]
 #include <hip/hip_runtime.h>
@@ -23,6 +24,7 @@ template <int CBSZ, int ABID, int BLGP> int run(const float *da, const float *db
             for (int j = 0; j < 4; j++) {
                 int ablk = blk, bblk = blk;
                 if (CBSZ == 2) ablk = (blk & ~3) | ABID;
+                if (CBSZ == 3) ablk = (blk & ~7) | ABID;
                 if (BLGP == 1) bblk = blk & 7;
                 if (BLGP == 2) bblk = (blk & 7) | 8;
                 const float want = ha[4 * ablk + i] * hb[4 * bblk + j];
@@ -50,5 +52,8 @@ int main() {
     bad += run<0, 0, 2>(da, db, dd, ha, hb);
     bad += run<2, 1, 1>(da, db, dd, ha, hb);
     bad += run<2, 2, 2>(da, db, dd, ha, hb);
+    bad += run<3, 0, 0>(da, db, dd, ha, hb);
+    bad += run<3, 5, 1>(da, db, dd, ha, hb);
+    bad += run<3, 7, 2>(da, db, dd, ha, hb);
     return bad ? 1 : 0;
 }
