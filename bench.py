@@ -189,7 +189,7 @@ def main():
         L.set_profiling(False)
         kstats = {k: v for k, v in L.kernel_stats().items() if v[0] > 0}
     if rank == 0:
-        fl = kernel_flops(N, S, B, fused=not (args.flags & 64) and N <= 512 and B % 8 == 0 and B > 8)
+        fl = kernel_flops(N, S, B, fused=not (args.flags & 64) and N <= 512)
         mf = {k: v for k, v in kstats.items() if k in fl}
         if mf:
             dom = max(mf, key=lambda k: mf[k][1])

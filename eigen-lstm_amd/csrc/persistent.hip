@@ -1521,6 +1521,7 @@ static bool fwd_second_form(int N) {
 // the second / first
 bool fwd_uses_third_form(int N, int B, int n_cus) {
     static const int form = getenv("LSTM_HIP_FWD_FORM") ? atoi(getenv("LSTM_HIP_FWD_FORM")) : 3;
+    // B <= 8 (a single column group, e.g. the evaluator's B = 1) stays on the second form: no difference measured there
     return form == 3 && (N == 256 || N == 512 || N == 1024) && B > 8 && (N / 16) * ((B + 7) / 8) <= n_cus;
 }
 
@@ -1637,7 +1638,7 @@ bool bwd_uses_m4(int N, int cols, bool bf16) {
 int bwd_group_cols(int N, int B, int n_cus) {
     static const int force = getenv("LSTM_HIP_BWD_COLS") ? atoi(getenv("LSTM_HIP_BWD_COLS")) : 0;
     if (force == 8 || force == 16) return force;
-    return (N / 16) * ((B + 7) / 8) <= n_cus && B > 8 ? 8 : 16;
+    return (N / 16) * ((B + 7) / 8) <= n_cus ? 8 : 16;
 }
 // floats in one column group's partial gradient block [dW | dU | db]
 size_t bwd_partial_floats(int N) { return (size_t)4 * N * 256 + (size_t)4 * N * N + (size_t)4 * N + (size_t)256 * N; }

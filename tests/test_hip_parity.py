@@ -31,6 +31,8 @@ CASES = [
     (1024, 4, 16, ()),                   # widest persistent instantiation (BASELINE configs[4] hidden size, fp32)
     (64, 2, 16, ()),                     # persistent engine with a single timestep
     (64, 3, 9, ((1, 8),)),               # ... two timesteps, ragged batch
+    (256, 6, 3, ()),                     # fewer streams than one 8-column group
+    (512, 5, 8, ((2, 7),)),              # exactly one 8-column group
 ]
 
 
