@@ -126,5 +126,7 @@ void eval_bits(const float *P, int N, const uint8_t *text, uint64_t len, double 
                hipStream_t st);
 void sample(const float *P, int N, float *hc /*2N*/, const double *u, int count, uint8_t *out, float *scratch,
             hipStream_t st);
+void sample_head(const float *Why, const float *by, int N, const float *hvec, const double *u, uint8_t *out, int32_t *x_next,
+                 hipStream_t st);
 
 } // namespace lstmk

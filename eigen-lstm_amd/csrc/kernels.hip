@@ -1208,6 +1208,49 @@ __global__ __launch_bounds__(1024) void k_sample(const float *__restrict__ P, in
         hc[N + j] = cs[j];
     }
 }
+// One character of the sampler for the multi-workgroup path (lstm_hip_api.cpp: per character this kernel, then one
+// k_fwd_step launch with the sampled byte as input): probabilities from h exactly as b1_output / k_sample compute them,
+// then the sequential float CDF walk of R/lstm.cc:321-338.  The byte goes to out[0] and, as the next input index, to
+// x_next[0].
+__global__ __launch_bounds__(256) void k_sample_head(const float *__restrict__ Why, const float *__restrict__ by, int N,
+                                                     const float *__restrict__ hvec, const double *__restrict__ u,
+                                                     uint8_t *__restrict__ out, int32_t *__restrict__ x_next) {
+    __shared__ float ps[256];
+    __shared__ float hs[1024];
+    const int m = threadIdx.x;
+    for (int k = m; k < N; k += 256) hs[k] = hvec[k];
+    __syncthreads();
+    float y = 0.0f;
+    for (int k0 = 0; k0 < N; k0 += 16) { // 16 loads in flight; the additions stay in k order (as b1_output)
+        float wv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) wv[i] = Why[(size_t)(k0 + i) * 256 + m];
+#pragma unroll
+        for (int i = 0; i < 16; i++) y += wv[i] * hs[k0 + i];
+    }
+    ps[m] = expf(y + by[m]);
+    __syncthreads();
+    if (m == 0) {
+        float s = 0.0f;
+        for (int i = 0; i < 256; i++) s += ps[i];
+        const float r = (float)u[0];
+        float cdf = 0.0f;
+        int index = 0;
+        for (int i = 0; i < 256; i++) {
+            cdf += ps[i] / s;
+            if (r < cdf) {
+                index = i;
+                break;
+            }
+        }
+        out[0] = (uint8_t)index;
+        x_next[0] = index;
+    }
+}
+void sample_head(const float *Why, const float *by, int N, const float *hvec, const double *u, uint8_t *out, int32_t *x_next,
+                 hipStream_t st) {
+    hipLaunchKernelGGL(k_sample_head, dim3(1), dim3(256), 0, st, Why, by, N, hvec, u, out, x_next);
+}
 void sample(const float *P, int N, float *hc, const double *u, int count, uint8_t *out, float *, hipStream_t st) {
     const size_t lds = (size_t)(6 * N + 256) * sizeof(float);
     hipLaunchKernelGGL(k_sample, dim3(1), dim3(1024), lds, st, P, N, hc, u, count, out);

@@ -808,6 +808,17 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
 // Where the persistent forward recurrence exists for this hidden size, the text is run through it in
 // chunks on an internal B = 1 handle (the carry moves from the last column of a chunk to column 0 of the
 // next); otherwise by the single-workgroup kernel.
+// internal B = 1 handle behind the evaluator and the sampler (its own copy of the parameters and their fragment images)
+static const int AUX_S = 129; // 128 characters per evaluator chunk
+static int ensure_aux_handle(lstm_hip_ctx *h) {
+    if (h->eval_h) return 0;
+    lstm_hip_config c = h->cfg;
+    c.S = AUX_S;
+    c.B = 1;
+    c.flags = (h->cfg.flags & LSTM_HIP_FAST_MATH) | LSTM_HIP_NO_FUSED_GRADS;
+    return lstm_hip_create(&c, &h->eval_h);
+}
+
 int lstm_hip_eval_bits(lstm_hip_t *h, const uint8_t *text, size_t len, double *bits_per_char) {
     CHECK(h);
     if (!text || len < 2 || !bits_per_char) return fail(LSTM_HIP_EINVAL, "eval_bits: need >= 2 bytes and an output pointer");
@@ -825,13 +836,9 @@ int lstm_hip_eval_bits(lstm_hip_t *h, const uint8_t *text, size_t len, double *b
         return 0;
     }
     HIP_TRY(hipStreamSynchronize(h->st));
-    const int Se = 129; // 128 characters per chunk
-    if (!h->eval_h) {
-        lstm_hip_config c = h->cfg;
-        c.S = Se;
-        c.B = 1;
-        c.flags = (h->cfg.flags & LSTM_HIP_FAST_MATH) | LSTM_HIP_NO_FUSED_GRADS;
-        int rc = lstm_hip_create(&c, &h->eval_h);
+    const int Se = AUX_S;
+    {
+        int rc = ensure_aux_handle(h);
         if (rc) return rc;
     }
     lstm_hip_ctx *e = h->eval_h;
@@ -877,6 +884,33 @@ int lstm_hip_sample(lstm_hip_t *h, float *h0, float *c0, const double *u, int32_
     HIP_TRY(hipMemcpyAsync(d_hc, h0, sizeof(float) * N, hipMemcpyHostToDevice, h->st));
     HIP_TRY(hipMemcpyAsync(d_hc + N, c0, sizeof(float) * N, hipMemcpyHostToDevice, h->st));
     HIP_TRY(hipMemcpyAsync(d_u, u, sizeof(double) * count, hipMemcpyHostToDevice, h->st));
+    if (h->persistent && !(h->cfg.flags & LSTM_HIP_STEP_KERNELS) && count > 0) {
+        // Multi-workgroup path: per character one k_sample_head (probabilities + CDF walk, one workgroup) and one
+        // k_fwd_step launch (the recurrent product over N/4 workgroups) on the internal B = 1 handle the evaluator uses;
+        // the sampled byte never leaves the device.  (k_sample does the whole 4N x N product in ONE workgroup:
+        // 395 us per character at N = 512.)
+        HIP_TRY(hipStreamSynchronize(h->st));
+        int rc = ensure_aux_handle(h);
+        if (rc) return rc;
+        lstm_hip_ctx *e = h->eval_h;
+        HIP_TRY(hipMemcpyAsync(e->P, h->P, sizeof(float) * h->pl.total, hipMemcpyDeviceToDevice, e->st));
+        pack_U(e->P + e->pl.U, e->Ufwd, e->Ubwd, N, e->st);
+        e->packed = true;
+        HIP_TRY(hipMemcpyAsync(e->H, d_hc, sizeof(float) * N, hipMemcpyDeviceToDevice, e->st));
+        HIP_TRY(hipMemcpyAsync(e->C, d_hc + N, sizeof(float) * N, hipMemcpyDeviceToDevice, e->st));
+        const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
+        int cur = 0;
+        for (int i = 0; i < count; i++) {
+            sample_head(e->P + e->pl.Why, e->P + e->pl.by, N, e->H + (size_t)cur * N, d_u + i, d_out + i, e->xi, e->st);
+            fwd_step(e->Ufwd, e->P + e->pl.W, e->P + e->pl.b, e->H + (size_t)cur * N, e->C + (size_t)cur * N,
+                     e->H + (size_t)(cur ^ 1) * N, e->C + (size_t)(cur ^ 1) * N, e->G, e->xi, N, 1, fast, e->st);
+            cur ^= 1;
+        }
+        HIP_TRY(hipMemcpyAsync(d_hc, e->H + (size_t)cur * N, sizeof(float) * N, hipMemcpyDeviceToDevice, e->st));
+        HIP_TRY(hipMemcpyAsync(d_hc + N, e->C + (size_t)cur * N, sizeof(float) * N, hipMemcpyDeviceToDevice, e->st));
+        HIP_TRY(hipStreamSynchronize(e->st));
+        e->fwd_done = false;
+    } else
     sample(h->P, N, d_hc, d_u, count, d_out, nullptr, h->st);
     HIP_TRY(hipMemcpyAsync(h0, d_hc, sizeof(float) * N, hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipMemcpyAsync(c0, d_hc + N, sizeof(float) * N, hipMemcpyDeviceToHost, h->st));
