@@ -189,7 +189,9 @@ def main():
         L.set_profiling(False)
         kstats = {k: v for k, v in L.kernel_stats().items() if v[0] > 0}
     if rank == 0:
-        fl = kernel_flops(N, S, B, fused=not (args.flags & 64) and N <= 512)
+        # the library fuses DHy / dWhy into the backward recurrence when it runs on 8-column groups (one workgroup per CU on
+        # the 256 CUs of an MI355X) and hidden <= 512
+        fl = kernel_flops(N, S, B, fused=not (args.flags & 64) and N <= 512 and (N // 16) * ((B + 7) // 8) <= 256)
         mf = {k: v for k, v in kstats.items() if k in fl}
         if mf:
             dom = max(mf, key=lambda k: mf[k][1])
