@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     // step-0 counter slots of its group; after the first wait every workgroup of the group reads the same NBK words
     // and takes the plain-store path only if they all agree.  The first publish is always sc1.
     unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE; // step index 0 is never a hand-off step (t = 1..S-1)
-    if (XCD_LOCAL && !BF16 && tid == 0)
+    if (XCD_LOCAL && tid == 0)
         __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT); // getreg(id 20 = XCC_ID, offset 0, size 4)
     unsigned ol_target = 0;
@@ -1241,7 +1241,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
         if (has_next && w == 0) {
             const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
             if (!wait_arrivals<BWD_SH>(cpn, NBK, epoch * EW, abortp, l, (stagger >> 8) & 0xffff) && l == 0) s_abort = 1;
-            if (XCD_LOCAL && !BF16 && t == S - 2) { // every workgroup of the group has published its XCC id by now
+            if (XCD_LOCAL && t == S - 2) { // every workgroup of the group has published its XCC id by now
                 bool same = true;
                 unsigned mine = 0;
                 for (int i = l; i < NBK; i += 64) {
@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
         }
         __syncthreads();
         if (s_abort) return;
-        if (XCD_LOCAL && !BF16 && t == S - 2) local_pub = s_local != 0; // decided by wave 0 just above; kept in a register
+        if (XCD_LOCAL && t == S - 2) local_pub = s_local != 0; // decided by wave 0 just above; kept in a register
         BSTAMP_AT(1)
 
         float dhn = 0.0f;
@@ -1407,10 +1407,11 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
             if (ecol < B) {
                 if (BF16) { // fp32 copy for the dU product (read after the launch); bf16 copy is the hand-off
                     *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
-                    if ((tq & 1) == 0)
-                        __builtin_amdgcn_raw_buffer_store_b128(
-                            pack_bf16x8(v, v2), rDG,
-                            (int)((((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) * sizeof(unsigned short)), 0, 16);
+                    if ((tq & 1) == 0) {
+                        const size_t eoff = ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq; // in bf16 elements
+                        if (XCD_LOCAL && local_pub) *reinterpret_cast<u32x4 *>(DGb + eoff) = pack_bf16x8(v, v2);
+                        else __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v, v2), rDG, (int)(eoff * sizeof(unsigned short)), 0, 16);
+                    }
                 } else {
                     if (XCD_LOCAL && local_pub)
                         *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
