@@ -370,6 +370,22 @@ template <bool TRANS, int ROWS, int NT> struct GemmTile {
             reg[q] = v;
         }
     }
+    // the same for a tile known to lie inside the operand (rows r0..r0+ROWS-1 < rmax, k0..k0+GBK-1 < kend): no predicates
+    __device__ static __forceinline__ void load_full(const float *__restrict__ src, int ld, int r0, int k0, int tid,
+                                                     float4 (&reg)[4]) {
+#pragma unroll
+        for (int q = 0; q < REPS; q++) {
+            if (!TRANS) {
+                constexpr int R4 = ROWS / 4, KSTEP = NT / R4;
+                const int r = r0 + (tid % R4) * 4, kk = tid / R4 + q * KSTEP;
+                if (REPS * KSTEP == GBK || kk < GBK) reg[q] = *reinterpret_cast<const float4 *>(src + (size_t)(k0 + kk) * ld + r);
+            } else {
+                constexpr int RSTEP = NT / K4;
+                const int k = k0 + (tid % K4) * 4, rr = tid / K4 + q * RSTEP;
+                if (REPS * RSTEP == ROWS || rr < ROWS) reg[q] = *reinterpret_cast<const float4 *>(src + (size_t)(r0 + rr) * ld + k);
+            }
+        }
+    }
     __device__ static __forceinline__ void store(float *lds, int tid, const float4 (&reg)[4]) {
 #pragma unroll
         for (int q = 0; q < REPS; q++) {
@@ -436,22 +452,16 @@ __global__ __launch_bounds__(128 * MW) void k_gemm(int M, int Nn, int K, const f
     float4 ra[4], rb[4];
     // op(A): TA=false -> A is M x K, m contiguous (direct); TA=true -> A stored K x M, k contiguous
     // op(B): TB=true  -> B stored Nn x K, n contiguous (direct); TB=false -> B is K x Nn, k contiguous
-    TileA::load(A, lda, m0, M, kbeg, kend, tid, ra);
-    TileB::load(Bm, ldb, n0, Nn, kbeg, kend, tid, rb);
-    TileA::store(As[0], tid, ra);
-    TileB::store(Bs[0], tid, rb);
-    __syncthreads();
-    int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-        const bool more = k0 + GBK < kend;
-        if (more) {
-            TileA::load(A, lda, m0, M, k0 + GBK, kend, tid, ra);
-            TileB::load(Bm, ldb, n0, Nn, k0 + GBK, kend, tid, rb);
-        }
-        const float *Ac = As[cur], *Bc = Bs[cur];
-        // every fragment of the k-tile is read before its first MFMA (one exposed LDS latency per tile; read
-        // step by step, each group of four MFMAs waited on its own ds_reads: lgkmcnt(0) eight times a tile)
-        float af[GBK / 2][2], bf[GBK / 2][NI];
+    //
+    // Pipeline, one barrier per k-tile: while the MFMAs of tile k run on fragments already in registers, the fragments
+    // of tile k+1 are read from the other LDS stage into a second register set and the global loads of tile k+2 are in
+    // flight; tile k+2 is stored over tile k's stage (whose fragments were read an iteration ago) before the barrier.
+    // (Reading a tile's fragments right after the barrier that publishes it leaves the matrix pipe idle while all
+    // eight waves queue on the LDS: 64 KB per k-tile, ~500 cycles, plus the read latency.)
+    const int ntiles = (kend - kbeg + GBK - 1) / GBK;
+    const bool inside_mn = m0 + BM <= M && n0 + GBN <= Nn;
+    auto read_frags = [&](int stage, float (&af)[GBK / 2][2], float (&bf)[GBK / 2][NI]) {
+        const float *Ac = As[stage], *Bc = Bs[stage];
 #pragma unroll
         for (int s2 = 0; s2 < GBK / 2; s2++) {
             const int k = 2 * s2 + (l >> 5);
@@ -460,6 +470,21 @@ __global__ __launch_bounds__(128 * MW) void k_gemm(int M, int Nn, int K, const f
 #pragma unroll
             for (int ni = 0; ni < NI; ni++) bf[s2][ni] = Bc[k * TileB::LD + wn * 32 * NI + ni * 32 + (l & 31)];
         }
+    };
+    auto tile_step = [&](int kt, float (&afc)[GBK / 2][2], float (&bfc)[GBK / 2][NI], float (&afn)[GBK / 2][2],
+                         float (&bfn)[GBK / 2][NI]) {
+        const bool more2 = kt + 2 < ntiles, more1 = kt + 1 < ntiles;
+        if (more2) {
+            const int kk = kbeg + (kt + 2) * GBK;
+            if (inside_mn && kk + GBK <= kend) { // interior tile: predicate-free loads (a few instructions, not a hundred)
+                TileA::load_full(A, lda, m0, kk, tid, ra);
+                TileB::load_full(Bm, ldb, n0, kk, tid, rb);
+            } else {
+                TileA::load(A, lda, m0, M, kk, kend, tid, ra);
+                TileB::load(Bm, ldb, n0, Nn, kk, kend, tid, rb);
+            }
+        }
+        if (more1) read_frags((kt + 1) & 1, afn, bfn);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s2 = 0; s2 < GBK / 2; s2++)
@@ -467,13 +492,30 @@ __global__ __launch_bounds__(128 * MW) void k_gemm(int M, int Nn, int K, const f
             for (int mi = 0; mi < 2; mi++)
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s2][ni], af[s2][mi], acc[mi][ni], 0, 0, 0);
-        if (more) {
-            TileA::store(As[cur ^ 1], tid, ra);
-            TileB::store(Bs[cur ^ 1], tid, rb);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfc[s2][ni], afc[s2][mi], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) {
+            TileA::store(As[kt & 1], tid, ra);
+            TileB::store(Bs[kt & 1], tid, rb);
         }
         __syncthreads();
-        cur ^= 1;
+    };
+    TileA::load(A, lda, m0, M, kbeg, kend, tid, ra);
+    TileB::load(Bm, ldb, n0, Nn, kbeg, kend, tid, rb);
+    TileA::store(As[0], tid, ra);
+    TileB::store(Bs[0], tid, rb);
+    if (ntiles > 1) {
+        TileA::load(A, lda, m0, M, kbeg + GBK, kend, tid, ra);
+        TileB::load(Bm, ldb, n0, Nn, kbeg + GBK, kend, tid, rb);
+        TileA::store(As[1], tid, ra);
+        TileB::store(Bs[1], tid, rb);
+    }
+    __syncthreads();
+    float af0[GBK / 2][2], bf0[GBK / 2][NI], af1[GBK / 2][2], bf1[GBK / 2][NI];
+    read_frags(0, af0, bf0);
+    for (int kt = 0; kt < ntiles; kt += 2) {
+        tile_step(kt, af0, bf0, af1, bf1);
+        if (kt + 1 < ntiles) tile_step(kt + 1, af1, bf1, af0, bf0);
     }
     // D[row][col] of the swapped product = C[m = col][n = row]
 #pragma unroll
