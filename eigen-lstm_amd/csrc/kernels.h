@@ -29,6 +29,14 @@ void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, f
 bool fwd_uses_third_form(int N, int B, int n_cus); // forward recurrence on 8-column groups (k_fwd_persistent3)
 void fwd_persistent3(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B, bool fast, hipStream_t st);
+// fourth form: the third form's decomposition with a data-as-flag hand-off through a ring of step slots Hx
+// (fwd_ring_floats(N, B) floats, filled with 0xFF bytes once and after an abort); ring_base starts at 0 and moves by
+// fwd_ring_advance() after every launch
+size_t fwd_ring_floats(int N, int B);
+int fwd_ring_advance(int ring_base, int S);
+void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
+                     float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
+                     int poll_cfg, hipStream_t st);
 bool bwd_uses_m4(int N, int cols, bool bf16); // backward recurrence on v_mfma_f32_4x4x1 (8-column groups, fp32)
 
 // ---- baseline engine: one launch per timestep -----------------------------------------------

@@ -104,6 +104,9 @@ struct lstm_hip_ctx {
     float4 *Ufwd = nullptr, *Ubwd = nullptr;
     float4 *Ubwd4 = nullptr; // weight image of the 4x4x1 backward form (kernels.hip, k_pack_U), when bwd_uses_m4
     float4 *Ufwd4 = nullptr; // ... of the third-form forward kernel, when fwd_uses_third_form
+    float *Hx = nullptr;     // fourth form: ring of hand-off slots (data-as-flag), sentinel-filled
+    int ring_base = 0;       // slot of step 0 in the next launch
+    int poll_cfg = 0;        // LSTM_HIP_FWD_POLL: bits 0-7 s_sleep between polls, 8-15 first delay of the non-gating waves
     bool packed = false;
     float *H = nullptr, *C = nullptr, *G = nullptr, *DG = nullptr, *Y = nullptr, *Pr = nullptr, *DHy = nullptr;
     float *dcnext = nullptr, *colloss = nullptr, *dby_part = nullptr, *slabs = nullptr;
@@ -196,6 +199,10 @@ int check_abort(lstm_hip_ctx *h) {
         HIP_TRY(hipMemsetAsync(h->abortp, 0, sizeof(unsigned), h->st));
         HIP_TRY(hipMemsetAsync(h->cnt, 0, 2 * h->cnt_bytes, h->st)); // counters are inconsistent after an abort
         h->fwd_epoch = h->bwd_epoch = 0;
+        if (h->Hx) { // and so is the hand-off ring
+            HIP_TRY(hipMemsetAsync(h->Hx, 0xff, sizeof(float) * fwd_ring_floats(h->cfg.N, h->cfg.B), h->st));
+            h->ring_base = 0;
+        }
         return fail(LSTM_HIP_ESTATE, "a persistent recurrence kernel timed out waiting for a hand-off (results invalid)");
     }
     return 0;
@@ -233,7 +240,11 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
                                                    h->cnt, h->abortp, h->fwd_epoch, N, S, B, fast, h->st));
             return 0;
         }
-        if (h->Ufwd4)
+        if (h->Hx) {
+            RUN(K_FWD_PERSIST, fwd_persistent4(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
+                                               h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st));
+            h->ring_base = fwd_ring_advance(h->ring_base, S);
+        } else if (h->Ufwd4)
             RUN(K_FWD_PERSIST, fwd_persistent3(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->cnt,
                                                h->abortp, h->fwd_epoch, N, S, B, fast, h->st));
         else
@@ -519,7 +530,15 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
     if (h->persistent && bwd_uses_m4((int)N, h->bwd_cols, h->bf16)) ALLOC(h->Ubwd4, N * N);
     if (h->persistent && !h->bf16 && !(cfg->flags & (LSTM_HIP_GRANULE_HANDOFF | LSTM_HIP_DEBUG_STAMPS)) &&
         fwd_uses_third_form((int)N, (int)B, prop.multiProcessorCount))
+    {
         ALLOC(h->Ufwd4, N * N);
+        const char *e = getenv("LSTM_HIP_FWD_FORM"); // 3: counter hand-off (third form); default: data-as-flag (fourth)
+        if (!(e && atoi(e) == 3)) {
+            ALLOC(h->Hx, fwd_ring_floats((int)N, (int)B));
+            HIP_TRY(hipMemset(h->Hx, 0xff, sizeof(float) * fwd_ring_floats((int)N, (int)B)));
+            h->poll_cfg = getenv("LSTM_HIP_FWD_POLL") ? atoi(getenv("LSTM_HIP_FWD_POLL")) : 1;
+        }
+    }
     if (h->persistent && !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512) // larger N: the dU tiles no longer fit the VGPRs
         ALLOC(h->gpart, (size_t)((B + h->bwd_cols - 1) / h->bwd_cols) * bwd_partial_floats(cfg->N));
     // followers need whole MFMA k-tiles and whole softmax waves per time chunk
@@ -552,7 +571,7 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     (void)hipStreamSynchronize(h->st);
     if (h->st2) (void)hipStreamSynchronize(h->st2);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-    void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->Ubwd4, h->Ufwd4, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
+    void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->Ubwd4, h->Ufwd4, h->Hx, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
                     h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->Hg, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);

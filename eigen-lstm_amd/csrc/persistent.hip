@@ -569,6 +569,218 @@ __global__ __launch_bounds__(512) void k_fwd_persistent3(const float4 *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward recurrence, fourth form: the decomposition and arithmetic of the third form, but the hand-off carries no
+// counter, no drain and no poll -> barrier -> load sequence: THE DATA IS THE FLAG (Guideline 16, recipe R2, with the
+// tag folded into the value space).  h_t is published into a ring of HX_RING = 4 step slots Hx[slot][B][N] whose
+// words hold the sentinel 0xFFFFFFFF (a NaN pattern no computed h can have; a NaN input with that payload is
+// canonicalised on the way in) until the producer overwrites them, each word exactly once per use of the slot.  A
+// consuming WAVE re-issues the sc1 loads of its own K-slice -- the loads it needs anyway -- until no word is the
+// sentinel, then goes straight to its MFMAs: per step one store -> L2 -> load hop instead of store, drain, atomic,
+// poll, barrier, load.  Torn 16-byte stores cannot matter: every dword is checked by the lane that consumes it.
+//
+// Slot reuse.  Step t reads slot(t-1), publishes into slot(t) and, right after publishing, resets its own words of
+// slot(t+2) to the sentinel (slot(s) = (s + ring_base) & 3).  Safe because
+//   * the reset happens after the workgroup barrier of step t, which every wave reaches only after its poll of
+//     slot(t-1) succeeded, i.e. after EVERY workgroup of the group has published h_{t-1}, which each does after its
+//     own barrier of step t-1, i.e. after it finished reading slot(t-2) = slot(t+2): nobody still reads the old words;
+//   * a wave polls producer P's words of slot(t+2) (in step t+3) only after it consumed P's words of slot(t+1), which
+//     P stored after an s_waitcnt vmcnt(0) that covers the reset it issued a step earlier: the reset is visible first.
+// At the end of a launch slots S and S+1 hold the sentinel; the next launch starts with ring_base advanced by S-1 so
+// that these are its slots 1 and 2 (the two that no in-launch reset precedes).  The host fills the ring with the
+// sentinel once (and after an abort).  Step 1 reads the carry column H[0], written before the launch.
+// The time-batched products read the plain H, stored off the chain.  One workgroup barrier per step (the K-slice
+// reduction), `red` double-buffered by step parity.  XCD-local plain stores as in the third form (verified per launch).
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned HX_SENT = 0xFFFFFFFFu;
+constexpr int HX_RING = 4;
+__device__ __forceinline__ bool hx_ready(const float4 &v) {
+    return __float_as_uint(v.x) != HX_SENT && __float_as_uint(v.y) != HX_SENT && __float_as_uint(v.z) != HX_SENT &&
+           __float_as_uint(v.w) != HX_SENT;
+}
+__device__ __forceinline__ float hx_canon(float v) { return __float_as_uint(v) == HX_SENT ? __uint_as_float(0x7FC00000u) : v; }
+
+template <int NKQ, bool FAST>
+__global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restrict__ Ufwd4, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, float *H, float *__restrict__ C,
+                                                         float *__restrict__ G, const int32_t *__restrict__ xi, float *Hx,
+                                                         unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base,
+                                                         int S, int B, int poll_cfg) {
+    constexpr int N = 256 * NKQ, G4 = 4 * N, Kw = N / 8, NL = Kw / 32, RS = 136;
+    __shared__ float red[2][8 * 4 * RS]; // [step parity][wave][gate][column*16 + unit]
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int NB3 = gridDim.x, NG = gridDim.y;
+    const int lin_ = blockIdx.x + NB3 * blockIdx.y;
+    const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
+    const int lx = l >> 5, lu = (l >> 2) & 7, li = l & 3; // MFMA role: lane = 32x + 4u + i
+    const int mcol = 8 * g + 4 * lx + li, mcolc = mcol < B ? mcol : B - 1;
+    const int gc = (tid >> 4) & 7, gu = tid & 15; // gating role (waves 0, 1): tid = column*16 + unit
+    const int col = 8 * g + gc, colc = col < B ? col : B - 1;
+    const int j = 16 * kb + gu;
+
+    float4 wq[2][NL][2][2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++)
+#pragma unroll
+        for (int L = 0; L < NL; L++)
+#pragma unroll
+            for (int eh = 0; eh < 2; eh++)
+#pragma unroll
+                for (int sh = 0; sh < 2; sh++)
+                    wq[ps][L][eh][sh] = Ufwd4[(((((((size_t)kb * 8 + w) * 2 + ps) * NL + L) * 2 + eh) * 2 + sh) * 64) + l];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (w < 2) {
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
+        cprev = C[(size_t)colc * N + j];
+    }
+    const __amdgpu_buffer_rsrc_t rH = make_rsrc(H, (size_t)S * N * B * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rHx = make_rsrc(Hx, (size_t)HX_RING * N * B * sizeof(float));
+    unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
+    if (tid == 0) {
+        s_abort = 0;
+        if (XCD_LOCAL) {
+            __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // visible before anything this workgroup publishes
+        }
+    }
+    bool local_pub = false;
+    const int poll_sleep = poll_cfg & 255, poll_first = (poll_cfg >> 8) & 255;
+    __syncthreads();
+
+    for (int t = 1; t < S; t++) {
+        const int par = t & 1;
+        float wx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w < 2) {
+            const int x = xi[t * B + colc];
+            if (x >= 0) {
+#pragma unroll
+                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
+            }
+        }
+        float4 b[NL];
+        if (t == 1) {
+            const int off = (int)((((size_t)mcolc) * N + Kw * w + 4 * lu) * sizeof(float));
+#pragma unroll
+            for (int i = 0; i < NL; i++) b[i] = ld_sc1(rH, off + 128 * i);
+        } else {
+            const int slot = (t - 1 + ring_base) & (HX_RING - 1);
+            const int off = (int)((((size_t)slot * B + mcolc) * N + Kw * w + 4 * lu) * sizeof(float));
+            if (w >= 2)
+                for (int i = 0; i < poll_first; i++) __builtin_amdgcn_s_sleep(1); // the other waves cannot be early
+            bool ok = false;
+            for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                bool good = true;
+#pragma unroll
+                for (int i = 0; i < NL; i++) {
+                    b[i] = ld_sc1(rHx, off + 128 * i);
+                    good = good && hx_ready(b[i]);
+                }
+                if (__all(good)) {
+                    ok = true;
+                    break;
+                }
+                if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                for (int i = 0; i < poll_sleep; i++) __builtin_amdgcn_s_sleep(1); // 64 cycles each
+            }
+            if (!ok && l == 0) {
+                __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_abort = 1;
+            }
+        }
+        f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
+#define F4_HALF(av, q0, q1, s0, blgp)                                                   \
+    c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.x, c00, 3, s0 + 0, blgp);          \
+    c10 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.x, c10, 3, s0 + 0, blgp);          \
+    c01 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.y, c01, 3, s0 + 1, blgp);          \
+    c11 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.y, c11, 3, s0 + 1, blgp);          \
+    c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.z, c00, 3, s0 + 2, blgp);          \
+    c10 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.z, c10, 3, s0 + 2, blgp);          \
+    c01 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.w, c01, 3, s0 + 3, blgp);          \
+    c11 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.w, c11, 3, s0 + 3, blgp);
+#define F4_STEP(av, L, eh, blgp)                             \
+    F4_HALF(av, wq[0][L][eh][0], wq[1][L][eh][0], 0, blgp)   \
+    F4_HALF(av, wq[0][L][eh][1], wq[1][L][eh][1], 4, blgp)
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            F4_STEP(b[i].x, i, 0, 1)
+            F4_STEP(b[i].y, i, 0, 2)
+            F4_STEP(b[i].z, i, 1, 1)
+            F4_STEP(b[i].w, i, 1, 2)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef F4_STEP
+#undef F4_HALF
+        float *rp = red[par];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            rp[(w * 4 + li) * RS + (4 * lx + r) * 16 + lu] = c00[r] + c01[r];
+            rp[(w * 4 + li) * RS + (4 * lx + r) * 16 + 8 + lu] = c10[r] + c11[r];
+        }
+        __syncthreads();
+        if (s_abort) return;
+
+        if (w < 2) {
+            if (XCD_LOCAL && t == 2) { // every workgroup of the group has published h_1, hence its XCC id before it
+                unsigned mine = 0;
+                bool same = true;
+                if (l < NB3) {
+                    mine = __hip_atomic_load(xcc_tab + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    same = (mine >> 4) == epoch;
+                }
+                const unsigned first = __builtin_amdgcn_readfirstlane(mine);
+                if (l < NB3) same = same && mine == first;
+                local_pub = (XCD_FORCE_LOCAL || __all(same)) && NB3 <= 64;
+            }
+            float pre[4];
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) {
+                float uh = rp[(0 * 4 + gt) * RS + tid];
+#pragma unroll
+                for (int ww = 1; ww < 8; ww++) uh += rp[(ww * 4 + gt) * RS + tid];
+                pre[gt] = (wx[gt] + uh) + bs[gt]; // R/lstm.cc:176
+            }
+            const float ig = p_sigm<FAST>(pre[0]), og = p_sigm<FAST>(pre[1]), fg = p_sigm<FAST>(pre[2]); // :179
+            const float ug_ = p_tanh<FAST>(pre[3]);                                                       // :182
+            const float cv = p_tanh<FAST>(ig * ug_ + fg * cprev);                                         // :185-189
+            const float hv = og * cv;                                                                     // :192
+            cprev = cv;
+            float4 h4;
+            h4.x = dpp_f<0x00>(hv);
+            h4.y = dpp_f<0x55>(hv);
+            h4.z = dpp_f<0xAA>(hv);
+            h4.w = dpp_f<0xFF>(hv);
+            // the reset this wave issued a step ago (and every older store) has completed before h_t can be seen
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((gu & 3) == 0 && col < B) {
+                const float4 hp = {hx_canon(h4.x), hx_canon(h4.y), hx_canon(h4.z), hx_canon(h4.w)};
+                const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
+                                     __uint_as_float(HX_SENT)};
+                const size_t e_pub = ((size_t)((t + ring_base) & (HX_RING - 1)) * B + col) * N + j;
+                const size_t e_rst = ((size_t)((t + 2 + ring_base) & (HX_RING - 1)) * B + col) * N + j;
+                if (XCD_LOCAL && local_pub) {
+                    *reinterpret_cast<float4 *>(Hx + e_pub) = hp;
+                    *reinterpret_cast<float4 *>(Hx + e_rst) = sent;
+                } else {
+                    st_sc1(hp, rHx, (int)(e_pub * sizeof(float)));
+                    st_sc1(sent, rHx, (int)(e_rst * sizeof(float)));
+                }
+                *reinterpret_cast<float4 *>(H + ((size_t)t * B + col) * N + j) = h4;
+            }
+            if (col < B) {
+                float *gcp = G + ((size_t)t * B + col) * G4 + j;
+                gcp[0] = ig;
+                gcp[N] = og;
+                gcp[2 * N] = fg;
+                gcp[3 * N] = ug_;
+                C[((size_t)t * B + col) * N + j] = cv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 recurrence (LSTM_HIP_BF16_RECURRENCE, BASELINE configs[4]): the operands of U*h_prev are bfloat16
 // (round-to-nearest-even of the fp32 master weights and of the published h), the accumulation is fp32,
 // everything else is the fp32 kernel above.  MFMA 16x16x32 bf16: A[row=l&15][k=8*(l>>4)+j],
@@ -1521,9 +1733,10 @@ static bool fwd_second_form(int N) {
 // third form (k_fwd_persistent3): 8-column groups, one workgroup per CU; N = 256, 512, 1024; LSTM_HIP_FWD_FORM=2 / 1 keep
 // the second / first
 bool fwd_uses_third_form(int N, int B, int n_cus) {
-    static const int form = getenv("LSTM_HIP_FWD_FORM") ? atoi(getenv("LSTM_HIP_FWD_FORM")) : 3;
+    static const int form = getenv("LSTM_HIP_FWD_FORM") ? atoi(getenv("LSTM_HIP_FWD_FORM")) : 4;
     // B <= 8 (a single column group, e.g. the evaluator's B = 1) stays on the second form: no difference measured there
-    return form == 3 && (N == 256 || N == 512 || N == 1024) && B > 8 && (N / 16) * ((B + 7) / 8) <= n_cus;
+    // (4, the default, = the same decomposition with the data-as-flag hand-off, k_fwd_persistent4)
+    return form >= 3 && (N == 256 || N == 512 || N == 1024) && B > 8 && (N / 16) * ((B + 7) / 8) <= n_cus;
 }
 
 bool persistent_supported(int N, int B, int n_cus) {
@@ -1538,7 +1751,13 @@ bool persistent_supported(int N, int B, int n_cus) {
             X(1) X(2) X(4)
 #undef X
         }
-        if (fb < 1) return false;
+        int fb4 = 0;
+        switch (N / 256) {
+#define X(k) case k: fb4 = blocks_per_cu(k_fwd_persistent4<k, false>, 512); break;
+            X(1) X(2) X(4)
+#undef X
+        }
+        if (fb < 1 || fb4 < 1) return false;
         fb = 1; // the form is chosen only when one workgroup per CU suffices
     } else if (fwd_second_form(N)) {
         fwd_tiles = N / 8;
@@ -1608,6 +1827,23 @@ void fwd_persistent3(const float4 *Ufwd4, const float *W, const float *bias, flo
     case k:                                                                                                           \
         if (fast) hipLaunchKernelGGL((k_fwd_persistent3<k, true>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B); \
         else hipLaunchKernelGGL((k_fwd_persistent3<k, false>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B);    \
+        break;
+        X(1) X(2) X(4)
+#undef X
+    }
+}
+
+size_t fwd_ring_floats(int N, int B) { return (size_t)HX_RING * N * B; }
+int fwd_ring_advance(int ring_base, int S) { return (ring_base + S - 1) & (HX_RING - 1); }
+void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
+                     float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
+                     int poll_cfg, hipStream_t st) {
+    const dim3 grid(N / 16, (B + 7) / 8), block(512);
+    switch (N / 256) {
+#define X(k)                                                                                                          \
+    case k:                                                                                                           \
+        if (fast) hipLaunchKernelGGL((k_fwd_persistent4<k, true>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch, ring_base, S, B, poll_cfg); \
+        else hipLaunchKernelGGL((k_fwd_persistent4<k, false>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch, ring_base, S, B, poll_cfg);    \
         break;
         X(1) X(2) X(4)
 #undef X

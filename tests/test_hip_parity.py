@@ -186,6 +186,32 @@ def test_known_answer_fixtures_through_the_gpu_evaluator():
         assert abs(bits - float(fx["expected_bits"])) <= 1e-4, (name, bits)
 
 
+@pytest.mark.parametrize("name,S", [("A", 26), ("B", 26), ("A", 101)])
+def test_known_answer_fixtures_through_hip_forward_and_loss(name, S):
+    """Fixtures A and B through lstm_hip_forward + lstm_hip_loss (the window operator, B = 1, windows chained through the
+    carry), not through the evaluator: the logged 3.24396 / 2.75851 bits/char within 1e-4.
+    Mirrors OV/lstm_eigen_class_CUDA/lstm.cc:661-720."""
+    import lstm_hip
+    from test_oracle_pinning import chained_windows_bits
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fx = np.load(os.path.join(gold, f"fixture_{name}.npz"))
+    N = int(fx["N"])
+    L = lstm_hip.Lstm(N, S, 1)
+    L.set_params(fx["params"])
+
+    def fwd(xi, ti, h0, c0, steps):
+        L.set_state(0, h0, c0)
+        L.set_window(xi, ti)
+        L.forward()
+        bits = L.loss()
+        h, c = L.get_state(steps)
+        return bits, h, c
+
+    bits = chained_windows_bits(fwd, N, fx["text"], S)
+    L.close()
+    assert abs(bits - float(fx["expected_bits"])) <= 1e-4, (name, S, bits)
+
+
 def test_sampler_matches_oracle(oracle32):
     import lstm_hip
     N = 32

@@ -28,6 +28,43 @@ def test_known_answer_fixture(name, oracle32, oracle64):
         assert abs(bits - float(fx["expected_bits"])) <= 1e-4, (name, orc.kind, bits)
 
 
+def chained_windows_bits(forward_fn, N, text, S):
+    """The reference's test() (OV/lstm_eigen_class_CUDA/lstm.cc:661-720) expressed with the WINDOW operator instead of
+    the one-stream loop: the text is cut into windows of S-1 steps (B = 1), h = c = 0 at the start (reset_std = 0,
+    lstm.cc:45,676-677), the last column of a window is the carry of the next; past the end of the text the columns are
+    empty (index -1: no input, no loss).  forward_fn(xi, ti, h0, c0) -> (window loss in bits, h_carry, c_carry) where
+    the carry is the state after the window's last real character.  Returns bits/char."""
+    h = np.zeros((1, N), np.float32)
+    c = np.zeros((1, N), np.float32)
+    total = 0.0
+    for pos in range(0, len(text) - 1, S - 1):
+        steps = min(S - 1, len(text) - 1 - pos)
+        xi = np.full((S, 1), -1, np.int32)
+        ti = np.full((S, 1), -1, np.int32)
+        xi[1:steps + 1, 0] = text[pos:pos + steps]
+        ti[1:steps + 1, 0] = text[pos + 1:pos + steps + 1]
+        bits, h, c = forward_fn(xi, ti, h, c, steps)
+        total += bits
+    return total / (len(text) - 1)
+
+
+@pytest.mark.parametrize("name,S", [("A", 26), ("B", 26), ("A", 101), ("B", 8)])
+def test_known_answer_fixture_through_the_window_forward(name, S, oracle32):
+    """Fixtures A/B through ref_forward -- the function every window parity test compares the HIP path with -- and not
+    only through the separate one-stream loop ref_eval_bits: same logged bits/char, same 1e-4 tolerance."""
+    fx = np.load(os.path.join(GOLD, f"fixture_{name}.npz"))
+    N, M = int(fx["N"]), int(fx["M"])
+
+    def fwd(xi, ti, h0, c0, steps):
+        fw = oracle32.forward(N, M, S, 1, fx["params"], xi, ti, h0, c0)
+        return fw["loss_bits"], fw["h"][steps].copy(), fw["c"][steps].copy()
+
+    bits = chained_windows_bits(fwd, N, fx["text"], S)
+    assert abs(bits - float(fx["expected_bits"])) <= 1e-4, (name, S, bits)
+    # and the two oracle entry points agree with each other far more tightly than with the 6-digit weight text
+    assert abs(bits - oracle32.eval_bits(N, M, fx["params"], fx["text"])) <= 2e-6
+
+
 def _random_case(orc, N, S, B, seed, M=256, scale=0.3):
     rs = np.random.RandomState(seed)
     P = (rs.randn(orc.param_count(N, M)) * scale).astype(orc.np_t)
