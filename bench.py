@@ -37,6 +37,22 @@ if os.environ.get("LSTM_BENCH_FAKE_GPU") == "1":  # CPU test of the multi-rank p
 METRIC = "chars/sec fwd+BPTT, enwik6 H=512 S=100 B=64, 1/2/4/8 GPU"
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
 
+# BASELINE.json `configs`, by index.  The corpora are synthetic stand-ins of the named file's length (enwik6's order-0
+# byte statistics): /root/reference does not travel to the GPU box, enwik7 is absent even there, and the
+# throughput does not depend on the content.  configs[3] is configs[2] under `--gpus 8` (the driver's run).
+CONFIGS = {
+    0: dict(label="configs[0]: alice29.txt, hidden=128 seq=25 batch=1, fp32 (the `lstm.cc as-is` row)", N=128, S=25, B=1,
+            nbytes=152_089, corpus="alice29"),
+    1: dict(label="configs[1]: enwik5.txt, hidden=256 seq=50 batch=32, fp32", N=256, S=50, B=32, nbytes=100_000,
+            corpus="enwik5"),
+    2: dict(label="configs[2] (headline): enwik6.txt, hidden=512 seq=100 batch=64, fp32", N=512, S=100, B=64,
+            nbytes=1_000_000, corpus="enwik6"),
+    3: dict(label="configs[3]: enwik6.txt, hidden=512 seq=100 batch=512 sharded 8 ways (64/GPU), fp32", N=512, S=100, B=64,
+            nbytes=1_000_000, corpus="enwik6"),
+    4: dict(label="configs[4]: enwik7.txt, hidden=1024 seq=100 batch=128 over 8 GPUs (16/GPU), bf16 MFMA path", N=1024,
+            S=100, B=16, nbytes=10_000_000, corpus="enwik7", bf16=True),
+}
+
 
 def synthetic_text(n_bytes, seed=0):
     hist = json.load(open(os.path.join(ROOT, "bench_data", "enwik6_byte_hist.json")))["counts"]
@@ -118,9 +134,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--hidden", type=int, default=512)
-    ap.add_argument("--seq", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=64, help="streams per GPU (weak scaling)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs[i]; 2 (default) is the configuration the metric is quoted on")
+    ap.add_argument("--hidden", type=int, default=None, help="override the config's hidden size")
+    ap.add_argument("--seq", type=int, default=None, help="override the config's window length")
+    ap.add_argument("--batch", type=int, default=None, help="override: streams per GPU (weak scaling)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="after the K timed steps, a second timed region of at least this many seconds (0 = skip)")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--lr", type=float, default=0.01,
                     help="Adagrad step; 0.1 (R/lstm.cc:59) overflows the unshifted softmax at hidden=512 batch=64 "
                          "within ~100 windows unless the class_CUDA warm-up (lr=0 for 50*S windows) is used")
@@ -141,19 +162,33 @@ def main():
     import dp
     import lstm_hip
 
+    cfg = CONFIGS[args.config]
+    if cfg.get("bf16"):
+        args.bf16 = True
     if args.bf16:
         args.flags |= 128  # LSTM_HIP_BF16_RECURRENCE
-    N, S, B, lr = args.hidden, args.seq, args.batch, args.lr
+    N = args.hidden or cfg["N"]
+    S = args.seq or cfg["S"]
+    B = args.batch or cfg["B"]
+    lr = args.lr
     rdzv = dp.Rendezvous(rank, world, tag=os.environ.get("MASTER_PORT", "0") + "_" + os.environ.get("TORCHELASTIC_RUN_ID", "0"))
 
-    text = synthetic_text(1_000_000, seed=0)
+    text = synthetic_text(cfg["nbytes"], seed=0)
     L = lstm_hip.Lstm(N, S, B, device=local_rank, flags=args.flags)
     rng = lstm_hip.MT19937Normal(1)
     L.set_params(lstm_hip.init_params(rng, N))  # identical on every rank
     srng = lstm_hip.MT19937Normal(1000 + rank)
     L.set_state(1, srng.randn(N, B, 0.0, 0.1), srng.randn(N, B, 0.0, 0.1))  # becomes column 0 after the first slide
     L.set_text(text)
-    L.set_cursors(dp.cursors(len(text), S, rank, world, world * B))  # rank r owns streams [r*B, (r+1)*B)
+    # Steady state from the first timed window on, whatever --warmup is: the window is uploaded FULL, as S slides from the
+    # start cursors c0 would have left it (OV/lstm_eigen_opt/lstm.cc:190-213: target[t] = text[c0+t], x[t] = target[t-1]),
+    # and the cursors continue from c0 + S.  (The reference starts from an empty window and fills it over S iterations.)
+    c0 = dp.cursors(len(text), S, rank, world, world * B).astype(np.int64)  # rank r owns streams [r*B, (r+1)*B)
+    tt = np.arange(S, dtype=np.int64)[:, None]
+    ti0 = text[(c0[None, :] + tt) % len(text)].astype(np.int32)
+    xi0 = text[(c0[None, :] + tt - 1) % len(text)].astype(np.int32)
+    L.set_window(xi0, ti0)
+    L.set_cursors(((c0 + S) % len(text)).astype(np.uint64))
     L.set_global_batch(world * B)
     if world > 1:
         L.comm_init(rdzv.broadcast(lstm_hip.comm_unique_id() if rank == 0 else None), world, rank)
@@ -179,6 +214,23 @@ def main():
     chars = (S - 1) * B * args.steps * world
     value = chars / wall
 
+    # ---- sustained: a second, longer timed region (SURVEY 8d asks for >= 2 s of windows) ----------------------------
+    sustained = None
+    if args.sustained_seconds > 0:
+        n_sus = max(args.steps, int(np.ceil(args.sustained_seconds / (wall / args.steps))))
+        n_sus = int(rdzv.allgather(n_sus)[0]) if world > 1 else n_sus  # every rank runs rank 0's count
+        barrier()
+        t1 = time.perf_counter()
+        sl = L.train_windows(n_sus, lr, want_losses=True)
+        L.synchronize()
+        barrier()
+        wall_s = time.perf_counter() - t1
+        if world > 1:
+            wall_s = max(rdzv.allgather(wall_s))
+        sustained = {"steps": n_sus, "seconds": round(wall_s, 3), "ms_per_step": round(wall_s / n_sus * 1e3, 4),
+                     "value": round((S - 1) * B * n_sus * world / wall_s, 1),
+                     "loss_finite": bool(np.all(np.isfinite(sl)))}
+
     # ---- per-kernel durations, HIP events on the library's own stream (separate short pass) ----
     roofline = None
     kstats = {}
@@ -191,7 +243,8 @@ def main():
     if rank == 0:
         # the library fuses DHy / dWhy into the backward recurrence when it runs on 8-column groups (one workgroup per CU on
         # the 256 CUs of an MI355X) and hidden <= 512
-        fl = kernel_flops(N, S, B, fused=not (args.flags & 64) and N <= 512 and (N // 16) * ((B + 7) // 8) <= 256)
+        fl = kernel_flops(N, S, B, fused=not (args.flags & 64) and N <= 512 and N % 64 == 0 and
+                          (N // 16) * ((B + 7) // 8) <= 256)
         mf = {k: v for k, v in kstats.items() if k in fl}
         if mf:
             dom = max(mf, key=lambda k: mf[k][1])
@@ -210,23 +263,27 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": METRIC, "value": round(value, 1), "unit": "chars/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC if args.config in (2, 3) and (N, S, B) == (512, 100, 64) and not args.bf16
+            else f"chars/sec fwd+BPTT, hidden={N} seq={S} batch={B}/GPU",
+            "value": round(value, 1), "unit": "chars/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 recurrent MFMA (f32 accumulate, f32 elsewhere)" if args.flags & 128 else "f32",
             "data": ("FAKE GPU (plumbing test, not a measurement) " if getattr(lstm_hip, "FAKE", False) else "")
-                    + "synthetic (1e6 bytes, enwik6 order-0 byte statistics; random-init weights, seed 1)",
-            "config": {"workload": f"enwik6-shaped text, hidden={N} seq={S} batch={B}/GPU (global {B * world}), fp32, "
-                                   "stride-1 windows, Adagrad lr=%g" % lr,
+                    + f"synthetic ({len(text)} bytes, enwik6 order-0 byte statistics; random-init weights, seed 1)",
+            "config": {"workload": f"{cfg['label']}; run as hidden={N} seq={S} batch={B}/GPU (global {B * world}), "
+                                   f"{'bf16 recurrent MFMA' if args.bf16 else 'fp32'}, {cfg['corpus']}-sized synthetic text "
+                                   f"({len(text)} bytes), stride-1 windows from a full window, Adagrad lr=%g" % lr,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "engine": "step-kernels" if (args.flags & lstm_hip.STEP_KERNELS) else "default"},
             "device_ms_per_step": round(dev_ms / args.steps, 4),
             "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
+            "sustained": sustained,
             "roofline": roofline,
             "kernels_us": {k: [v[0] // max(args.profile_windows, 1), round(v[1] / v[0] * 1e3, 2)] for k, v in kstats.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, S, B, text, lr)
+            out["cpu_baseline"] = cpu_baseline(N, S, B, text, lr, budget_s=args.cpu_budget)
         print(json.dumps(out), flush=True)
     L.close()
     rdzv.barrier()

@@ -26,18 +26,8 @@ struct ParamLayout {
 // Ubwd[N/16][N/4][64] float4 : A-fragments of U^T for the backward product
 void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, float4 *Ubwd4 = nullptr,
             float4 *Ufwd4 = nullptr);
-bool fwd_uses_third_form(int N, int B, int n_cus); // forward recurrence on 8-column groups (k_fwd_persistent3)
-void fwd_persistent3(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
-                     unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B, bool fast, hipStream_t st);
-// fourth form: the third form's decomposition with a data-as-flag hand-off through a ring of step slots Hx
-// (fwd_ring_floats(N, B) floats, filled with 0xFF bytes once and after an abort); ring_base starts at 0 and moves by
-// fwd_ring_advance() after every launch
-size_t fwd_ring_floats(int N, int B);
-int fwd_ring_advance(int ring_base, int S);
-void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
-                     float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
-                     int poll_cfg, hipStream_t st);
-bool bwd_uses_m4(int N, int cols, bool bf16); // backward recurrence on v_mfma_f32_4x4x1 (8-column groups, fp32)
+bool fwd_uses_8col_form(int N, int B, int n_cus); // forward recurrence on 8-column groups (k_fwd_persistent4, Ufwd4 image)
+bool bwd_uses_m4(int N, int cols, bool bf16);     // backward recurrence on v_mfma_f32_4x4x1 (8-column groups, fp32, Ubwd4 image)
 
 // ---- baseline engine: one launch per timestep -----------------------------------------------
 // g = U*h_prev + W[:,x] + b ; gates ; c = tanh(i*u + f*c_prev) ; h = o*c      (R/lstm.cc:176-192)
@@ -48,30 +38,35 @@ void bwd_step(const float4 *Ubwd, const float *DGnext /*null at t=S-1*/, const f
               const float *C_t, const float *Cprev, float *dcnext, float *DG_t, int N, int B, hipStream_t st);
 
 // ---- default engine: each recurrence of a window as ONE persistent launch (persistent.hip) ----
-// Weights stay in VGPRs; steps are chained by sc1 stores + sharded device-scope counters.
-// `cnt` must hold persistent_counter_bytes() bytes (separate regions for fwd and bwd), zeroed once;
-// `epoch` = 1, 2, ... counts the launches that used that region (counters are cumulative);
-// `abortp` is one zeroed word that a timed-out spin sets.
+// Weights stay in VGPRs; the steps are chained inside the launch.  Hand-off, by form:
+//   8-column forward form and (optionally) the fp32 4x4x1 backward form: data-as-flag through a ring of sentinel-filled
+//     step slots (Hx / DGx; *_ring_floats() floats, filled with 0xFF bytes once and after an abort; ring_base starts at 0
+//     and moves by *_ring_advance() after every launch);
+//   every other form: sc1 stores + sharded device-scope counters.  `cnt` must hold persistent_counter_bytes() bytes
+//     (separate regions for fwd and bwd), zeroed once; `epoch` = 1, 2, ... counts the launches that used that region
+//     (counters are cumulative).  The ring forms use the step-0 slots of `cnt` for their XCD placement check.
+// `abortp` is one zeroed word that a timed-out spin sets.  `stamps` (diagnostic builds, N = 512 only): [2][S][16] u64.
 size_t persistent_counter_bytes(int S, int B);
-bool persistent_supported(int N, int B, int n_cus);
+bool persistent_supported(int N, int B, int n_cus, bool fused);      // fused: dW/db/DHy/dWhy inside the backward recurrence
+bool persistent_supported_bf16(int N, int B, int n_cus, bool fused); // the bf16 recurrence's own kernels and grids
 void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
                     const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B, bool fast,
-                    hipStream_t st, unsigned long long *stamps = nullptr);
-// granule hand-off form (LSTM_HIP_GRANULE_HANDOFF): Hg holds S*B*N 8-byte {value, tag} granules; epoch_base = S * window serial
-void fwd_persistent_granules(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
-                              unsigned long long *Hg, const int32_t *xi, unsigned *abortp, unsigned epoch_base, int N,
-                              int S, int B, bool fast, hipStream_t st);
-// follower support: a 1-wave kernel that returns once step `t` of launch `epoch` has been published by all
-// `n_prod` producers of every column group (or the abort word is set)
-void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, unsigned *abortp, hipStream_t st,
-                   bool backward = false, int arrivals = 1);
+                    hipStream_t st);
+size_t fwd_ring_floats(int N, int B);
+int fwd_ring_advance(int ring_base, int S);
+void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
+                     float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
+                     int poll_cfg, hipStream_t st, unsigned long long *stamps = nullptr);
 // gpart != null (8-column groups only): fused mode.  The recurrence then also produces DHy on the fly from
 // Why and dY (DHy is not read), and leaves per-column-group partial blocks [dW | - | db | dWhy]
 // (bwd_partial_floats(N) floats each) to be folded in group order; H and xi are read as well.
+// DGx != null (fp32 4x4x1 form only): data-as-flag hand-off through the ring.
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,
                     const int32_t *xi, float *gpart, const float *Why, const float *dY, unsigned *cnt, unsigned *abortp,
                     unsigned epoch, int N, int S, int B, int cols, hipStream_t st, unsigned long long *stamps = nullptr,
-                    unsigned short *DGb = nullptr);
+                    unsigned short *DGb = nullptr, float *DGx = nullptr, int ring_base = 0);
+size_t bwd_ring_floats(int N, int B);
+int bwd_ring_advance(int ring_base, int S);
 // bf16 recurrence (N % 128 == 0): bf16 fragment images of U (N*N*8 bytes each), h and dg also kept as bf16
 // hand-off copies Hb [S][B][N], DGb [S][B][4N]; bwd_persistent takes the Ubwd16 image as `Ubwd` and DGb != null
 void pack_U_bf16(const float *U, void *Ufwd16, void *Ubwd16, int N, hipStream_t st);
@@ -88,9 +83,7 @@ int bwd_group_cols(int N, int B, int n_cus); // 8 or 16 batch columns per backwa
 void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
           int splits, float *slabs, hipStream_t st);
 int gemm_pick_splits(int M, int Nn, int K);
-// one K-slice of a split-K product into slab z / the ordered fold of all slabs (time-chunked overlap)
-void gemm_slice(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *slabs,
-                int kchunk, int z, hipStream_t st);
+// the ordered fold of `splits` slabs
 // slab_stride: floats between consecutive slabs (0 = M*Nn, i.e. densely packed)
 void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st, size_t slab_stride = 0);
 

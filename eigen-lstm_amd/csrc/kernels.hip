@@ -513,6 +513,7 @@ __global__ __launch_bounds__(128 * MW) void k_gemm(int M, int Nn, int K, const f
     __syncthreads();
     float af0[GBK / 2][2], bf0[GBK / 2][NI], af1[GBK / 2][2], bf1[GBK / 2][NI];
     read_frags(0, af0, bf0);
+    __syncthreads(); // tile_step(0) stores tile 2 over stage 0: every wave's stage-0 fragments must be in registers first
     for (int kt = 0; kt < ntiles; kt += 2) {
         tile_step(kt, af0, bf0, af1, bf1);
         if (kt + 1 < ntiles) tile_step(kt + 1, af1, bf1, af0, bf0);
@@ -548,13 +549,11 @@ struct GemmShape {
     int bm, bn;
 };
 static GemmShape gemm_pick_shape(int M, int Nn, int K) {
-    static const int force_bm = getenv("LSTM_HIP_GEMM_BM") ? atoi(getenv("LSTM_HIP_GEMM_BM")) : 0;
     const int tiles128 = ((M + 127) / 128) * ((Nn + 127) / 128);
     GemmShape s;
     if (K >= 2048) s.bn = tiles128 >= 32 ? 128 : 64;
     else s.bn = tiles128 >= 192 ? 128 : 64;
     s.bm = (K >= 2048 && s.bn == 128 && M >= 1024) ? 256 : 128;
-    if (force_bm == 128 || (force_bm == 256 && s.bn == 128)) s.bm = force_bm;
     return s;
 }
 int gemm_pick_splits(int M, int Nn, int K) {
@@ -562,8 +561,6 @@ int gemm_pick_splits(int M, int Nn, int K) {
     const int tiles = ((M + sh.bm - 1) / sh.bm) * ((Nn + sh.bn - 1) / sh.bn);
     int splits = 1;
     // aim for >= ~512 workgroups (256 of the 8-wave ones), keep >= 8 k-tiles per split
-    static const int force = getenv("LSTM_HIP_GEMM_SPLITS") ? atoi(getenv("LSTM_HIP_GEMM_SPLITS")) : 0;
-    if (force > 0 && K >= 2048) return force;
     const int want = sh.bm == 256 ? 256 : 512;
     while (tiles * splits < want && K / (splits * 2) >= 8 * GBK) splits *= 2;
     return splits;
@@ -616,12 +613,6 @@ void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const
     if (splits > 1) gemm_reduce_launch(slabs, splits, M, Nn, C, ldc, st);
 }
 
-// One K-slice [z*kchunk, (z+1)*kchunk) of a split-K product into slab z (kchunk a multiple of 16); the
-// caller launches the slices as their inputs become available and folds them with gemm_fold.
-void gemm_slice(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *slabs,
-                int kchunk, int z, hipStream_t st) {
-    gemm_launch(TA, TB, M, Nn, K, A, lda, B, ldb, slabs, M, kchunk, (size_t)M * Nn, z, 1, st);
-}
 void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st, size_t slab_stride) {
     gemm_reduce_launch(slabs, splits, M, Nn, C, ldc, st, slab_stride);
 }

@@ -57,6 +57,8 @@ struct Rccl {
     int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr; // optional
+    int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -71,6 +73,8 @@ int rccl_load() {
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(lib, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(lib, "ncclGroupEnd");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
         return fail(LSTM_HIP_ERCCL, "librccl lacks a required symbol");
     g_rccl.lib = lib;
@@ -83,29 +87,27 @@ struct lstm_hip_ctx {
     lstm_hip_config cfg{};
     ParamLayout pl{};
     int T = 0; // (S-1)*B columns in the time-batched matrices
-    hipStream_t st = nullptr, st2 = nullptr; // st2: followers of the persistent recurrences (overlap mode)
-    hipStream_t st_b = nullptr;              // backward recurrence on one half of the CUs while st2 uses the other half
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_main = nullptr, ev_join = nullptr;
-    bool overlap = false;
-    int overlap_mask = 0;      // 1: forward followers, 2: backward followers, 4: CU-partitioned streams.  Measured
-                               // slower than serial in every combination, so off unless
-                               // LSTM_HIP_OVERLAP_MASK is set
-    int chunk_steps = 0;       // timesteps per follower chunk
-    float *slabs_dU = nullptr; // split-K slabs of dU (one per time chunk in overlap mode)
+    hipStream_t st = nullptr;
+    hipStream_t st2 = nullptr; // the early part of the gradient all-reduce runs here, beside the dU product on `st`
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    bool in_loop = false;       // inside lstm_hip_train_windows: nobody reads the gradient block between backward and Adagrad
+    bool early_reduced = false; // [dW] and [db | dWhy | dby] are already being all-reduced on st2 (ev_join marks the end)
+    float *slabs_dU = nullptr; // split-K slabs of dU
     bool bf16 = false;         // LSTM_HIP_BF16_RECURRENCE
     bool packed16 = false;
     unsigned short *Hb = nullptr, *DGb = nullptr; // bf16 hand-off copies of h and dg
     void *Ufwd16 = nullptr, *Ubwd16 = nullptr;    // bf16 fragment images of U
-    float *gpart = nullptr;    // per-column-group partial [dW|dU|db] blocks of the fused backward recurrence
-    bool dhy_done = false;
+    float *gpart = nullptr;    // per-column-group partial [dW|dU|db|dWhy] blocks of the fused backward recurrence
     int bwd_cols = 16;         // batch columns per backward-recurrence workgroup (8 or 16)
 
     float *P = nullptr, *dP = nullptr, *mem = nullptr;
     float4 *Ufwd = nullptr, *Ubwd = nullptr;
     float4 *Ubwd4 = nullptr; // weight image of the 4x4x1 backward form (kernels.hip, k_pack_U), when bwd_uses_m4
-    float4 *Ufwd4 = nullptr; // ... of the third-form forward kernel, when fwd_uses_third_form
-    float *Hx = nullptr;     // fourth form: ring of hand-off slots (data-as-flag), sentinel-filled
+    float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel, when fwd_uses_8col_form
+    float *Hx = nullptr;     // 8-column forward form: ring of hand-off slots (data-as-flag), sentinel-filled
     int ring_base = 0;       // slot of step 0 in the next launch
+    float *DGx = nullptr;    // backward recurrence: the same kind of ring for dg
+    int ring_base_b = 0;
     int poll_cfg = 0;        // LSTM_HIP_FWD_POLL: bits 0-7 s_sleep between polls, 8-15 first delay of the non-gating waves
     bool packed = false;
     float *H = nullptr, *C = nullptr, *G = nullptr, *DG = nullptr, *Y = nullptr, *Pr = nullptr, *DHy = nullptr;
@@ -130,11 +132,9 @@ struct lstm_hip_ctx {
     unsigned *cnt = nullptr;     // [2][persistent_counter_bytes]: fwd region, bwd region
     unsigned *abortp = nullptr;  // set by a timed-out spin inside a persistent kernel
     size_t cnt_bytes = 0;
-    unsigned long long *stamps = nullptr; // LSTM_HIP_DEBUG_STAMPS: [2][S][8] s_memtime values of the last forward
-    unsigned long long *Hg = nullptr; // h_t as {value, tag} granules for the forward hand-off
-    unsigned window_serial = 0;
+    unsigned long long *stamps = nullptr; // LSTM_HIP_DEBUG_STAMPS: [fwd, bwd][2 workgroups][S][16] s_memtime values
     int loss_mode = 0; // LSTM_HIP_LOSS_*
-    unsigned fwd_epoch = 0, bwd_epoch = 0; // launches so far on the cumulative hand-off counters       // epoch_base = S * serial; tags of earlier windows never match
+    unsigned fwd_epoch = 0, bwd_epoch = 0; // launches so far on the cumulative hand-off counters
 
     void *comm = nullptr;
     int nranks = 1, rank = 0;
@@ -199,19 +199,19 @@ int check_abort(lstm_hip_ctx *h) {
         HIP_TRY(hipMemsetAsync(h->abortp, 0, sizeof(unsigned), h->st));
         HIP_TRY(hipMemsetAsync(h->cnt, 0, 2 * h->cnt_bytes, h->st)); // counters are inconsistent after an abort
         h->fwd_epoch = h->bwd_epoch = 0;
-        if (h->Hx) { // and so is the hand-off ring
+        if (h->Hx) { // and so are the hand-off rings
             HIP_TRY(hipMemsetAsync(h->Hx, 0xff, sizeof(float) * fwd_ring_floats(h->cfg.N, h->cfg.B), h->st));
             h->ring_base = 0;
+        }
+        if (h->DGx) {
+            HIP_TRY(hipMemsetAsync(h->DGx, 0xff, sizeof(float) * bwd_ring_floats(h->cfg.N, h->cfg.B), h->st));
+            h->ring_base_b = 0;
         }
         return fail(LSTM_HIP_ESTATE, "a persistent recurrence kernel timed out waiting for a hand-off (results invalid)");
     }
     return 0;
 }
 
-// Overlap mode: while a persistent recurrence runs on `st`, the time-batched work that only needs the
-// steps already finished runs on `st2` behind k_wait_progress (forward: Y, softmax/loss/dY, DHy per
-// time chunk; backward: dWhy, the dW bucket sort, and dU one K-slice per time chunk).  Both streams
-// are joined before the function returns, so callers only ever see `st`.
 // reported loss: all S-1 steps in bits (R/lstm.cc:204-207) or the last step only in nats
 // (OV/lstm_eigen_class_CUDA/lstm.h:200-221); colloss holds -log2 p(target) per (step, column)
 const float *loss_src(const lstm_hip_ctx *h) {
@@ -220,59 +220,30 @@ const float *loss_src(const lstm_hip_ctx *h) {
 int loss_steps(const lstm_hip_ctx *h) { return h->loss_mode == LSTM_HIP_LOSS_LAST_STEP_NATS ? 1 : h->cfg.S - 1; }
 float loss_scale(const lstm_hip_ctx *h) { return h->loss_mode == LSTM_HIP_LOSS_LAST_STEP_NATS ? 0.693147180559945f : 1.0f; }
 
-bool overlap_now(const lstm_hip_ctx *h, int which /*1 fwd, 2 bwd*/) { return h->overlap && !h->profiling && (h->overlap_mask & which); }
-
 int launch_fwd_recurrence(lstm_hip_ctx *h) {
     const int N = h->cfg.N, B = h->cfg.B, S = h->cfg.S;
     const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
-    if (!(h->cfg.flags & LSTM_HIP_GRANULE_HANDOFF)) {
-        if (h->fwd_epoch >= (1u << 26)) { // keep epoch * arrivals inside 32 bits
-            HIP_TRY(hipMemsetAsync(h->cnt, 0, h->cnt_bytes, h->st));
-            h->fwd_epoch = 0;
+    if (h->fwd_epoch >= (1u << 26)) { // keep epoch * arrivals inside 32 bits
+        HIP_TRY(hipMemsetAsync(h->cnt, 0, h->cnt_bytes, h->st));
+        h->fwd_epoch = 0;
+    }
+    h->fwd_epoch++;
+    if (h->bf16) {
+        if (!h->packed16) {
+            RUN(K_PACK_U, pack_U_bf16(h->P + h->pl.U, h->Ufwd16, h->Ubwd16, N, h->st));
+            h->packed16 = true;
         }
-        h->fwd_epoch++;
-        if (h->bf16) {
-            if (!h->packed16) {
-                RUN(K_PACK_U, pack_U_bf16(h->P + h->pl.U, h->Ufwd16, h->Ubwd16, N, h->st));
-                h->packed16 = true;
-            }
-            RUN(K_FWD_PERSIST, fwd_persistent_bf16(h->Ufwd16, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi,
-                                                   h->cnt, h->abortp, h->fwd_epoch, N, S, B, fast, h->st));
-            return 0;
-        }
-        if (h->Hx) {
-            RUN(K_FWD_PERSIST, fwd_persistent4(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
-                                               h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st));
-            h->ring_base = fwd_ring_advance(h->ring_base, S);
-        } else if (h->Ufwd4)
-            RUN(K_FWD_PERSIST, fwd_persistent3(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->cnt,
-                                               h->abortp, h->fwd_epoch, N, S, B, fast, h->st));
-        else
-        RUN(K_FWD_PERSIST, fwd_persistent(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->cnt,
-                                          h->abortp, h->fwd_epoch, N, S, B, fast, h->st, h->stamps));
+        RUN(K_FWD_PERSIST, fwd_persistent_bf16(h->Ufwd16, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi,
+                                               h->cnt, h->abortp, h->fwd_epoch, N, S, B, fast, h->st));
+    } else if (h->Hx) {
+        RUN(K_FWD_PERSIST, fwd_persistent4(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
+                                           h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st, h->stamps));
+        h->ring_base = fwd_ring_advance(h->ring_base, S);
     } else {
-        h->window_serial++;
-        if ((unsigned long long)(h->window_serial + 1) * (unsigned)S >= 0xffffffffull) { // tag space exhausted: start over
-            HIP_TRY(hipMemsetAsync(h->Hg, 0, sizeof(unsigned long long) * (size_t)S * B * N, h->st));
-            h->window_serial = 1;
-        }
-        RUN(K_FWD_PERSIST, fwd_persistent_granules(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->Hg, h->xi,
-                                                   h->abortp, h->window_serial * (unsigned)S, N, S, B, fast, h->st));
+        RUN(K_FWD_PERSIST, fwd_persistent(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->cnt, h->abortp,
+                                          h->fwd_epoch, N, S, B, fast, h->st));
     }
     return 0;
-}
-
-// output layer for the columns of steps [ta, tb] on stream s: Y = Why*h (R/lstm.cc:195), softmax/loss/dy
-// (:199-207,225), and DHy = Why^T*dy (:228)
-void output_layer_chunk(lstm_hip_ctx *h, int ta, int tb, hipStream_t s) {
-    const int N = h->cfg.N, B = h->cfg.B;
-    const int col0 = (ta - 1) * B, col1 = tb * B, nc = col1 - col0;
-    float *Y1 = h->Y + (size_t)256 * B;
-    gemm(false, false, 256, nc, N, h->P + h->pl.Why, 256, h->H + (size_t)N * B + (size_t)col0 * N, N,
-         Y1 + (size_t)col0 * 256, 256, 1, nullptr, s);
-    softmax_loss_dy(Y1, h->Pr + (size_t)256 * B, h->P + h->pl.by, h->ti + B, h->colloss, h->dby_part, col0, col1, s);
-    gemm(true, false, N, nc, 256, h->P + h->pl.Why, 256, Y1 + (size_t)col0 * 256, 256,
-         h->DHy + (size_t)N * B + (size_t)col0 * N, N, 1, nullptr, s);
 }
 
 int do_forward(lstm_hip_ctx *h) {
@@ -284,26 +255,6 @@ int do_forward(lstm_hip_ctx *h) {
         h->packed = true;
     }
     h->n_dby_parts = softmax_parts(h->T);
-    h->dhy_done = false;
-    if (h->persistent && overlap_now(h, 1)) {
-        const int NG = (B + 15) / 16;
-        HIP_TRY(hipEventRecord(h->ev_fork, h->st));
-        HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
-        int rc = launch_fwd_recurrence(h);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(h->ev_main, h->st));
-        for (int ta = 1; ta < S; ta += h->chunk_steps) {
-            const int tb = ta + h->chunk_steps - 1 < S - 1 ? ta + h->chunk_steps - 1 : S - 1;
-            if (tb <= S - 2) wait_progress(h->cnt, tb, NG, N / 4, h->fwd_epoch, h->abortp, h->st2);
-            else HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_main, 0)); // the last step publishes nothing: wait for the launch
-            output_layer_chunk(h, ta, tb, h->st2);
-        }
-        HIP_TRY(hipEventRecord(h->ev_join, h->st2));
-        HIP_TRY(hipStreamWaitEvent(h->st, h->ev_join, 0));
-        h->dhy_done = true;
-        h->fwd_done = true;
-        return 0;
-    }
     if (h->persistent) {
         int rc = launch_fwd_recurrence(h);
         if (rc) return rc;
@@ -332,13 +283,11 @@ int do_backward(lstm_hip_ctx *h) {
         RUN(K_DBY, loss_reduce(loss_src(h), loss_steps(h), B, h->global_B, h->d_loss, h->dby_part, h->n_dby_parts,
                                h->dP + h->pl.by, h->st, loss_scale(h)));
     h->dby_done = false;
-    // DHy = Why^T * dY                 R/lstm.cc:228, all steps (already done by the forward's followers in overlap mode)
-    // fused mode: the backward recurrence produces DHy itself and accumulates dW, db, dWhy
-    const bool fused = h->persistent && h->gpart != nullptr && h->bwd_cols == 8 && !overlap_now(h, 2);
-    if (!h->dhy_done && !fused)
+    // fused mode: the backward recurrence produces DHy = Why^T * dY (R/lstm.cc:228) itself and accumulates dW, db, dWhy
+    const bool fused = h->persistent && h->gpart != nullptr && h->bwd_cols == 8;
+    if (!fused)
         RUN(K_GEMM_DHY, gemm(true, false, N, T, 256, h->P + h->pl.Why, 256, dY, 256, h->DHy + (size_t)N * B, N, 1, nullptr,
                              h->st));
-    h->dhy_done = false;
     unsigned *cb = h->cnt + h->cnt_bytes / sizeof(unsigned);
     if (h->persistent) {
         if (h->bwd_epoch >= (1u << 26)) {
@@ -346,47 +295,17 @@ int do_backward(lstm_hip_ctx *h) {
             h->bwd_epoch = 0;
         }
         h->bwd_epoch++;
-    }
-    if (h->persistent && overlap_now(h, 2)) {
-        hipStream_t sb = h->st_b ? h->st_b : h->st;
-        HIP_TRY(hipEventRecord(h->ev_fork, h->st));
-        HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
-        if (h->st_b) HIP_TRY(hipStreamWaitEvent(h->st_b, h->ev_fork, 0));
-        bwd_persistent(h->Ubwd4 ? h->Ubwd4 : h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, nullptr, nullptr, nullptr, cb, h->abortp,
-                       h->bwd_epoch, N, S, B, h->bwd_cols, sb);
-        HIP_TRY(hipEventRecord(h->ev_main, sb));
-        // Followers must not be dispatched before every workgroup of the recurrence has been placed
-        // (otherwise the dispatcher packs recurrence workgroups unevenly around them and the whole
-        // chain runs at the pace of the most crowded CU): the first published step proves that.
-        const int NGb = (B + h->bwd_cols - 1) / h->bwd_cols;
-        if (S - 1 >= 2) wait_progress(cb, S - 1, NGb, N / 16, h->bwd_epoch, h->abortp, h->st2, true, h->bwd_cols / 4);
-        // independent of the recurrence: dWhy = dY * H^T (R/lstm.cc:226) and the dW bucket sort
-        gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256, h->splits_dWhy, h->slabs,
-             h->st2);
-        dW_sort(h->xi + B, T, G4, h->dw_scratch, h->st2);
-        // dU = DG * H[0..S-2]^T (R/lstm.cc:250), one K-slice per time chunk, latest steps first
-        const int kchunk = h->chunk_steps * B, nz = (S - 1 + h->chunk_steps - 1) / h->chunk_steps;
-        for (int z = nz - 1; z >= 0; z--) {
-            const int ta = z * h->chunk_steps + 1; // earliest step of the slice = last one the recurrence reaches
-            if (ta >= 2) wait_progress(cb, ta, NGb, N / 16, h->bwd_epoch, h->abortp, h->st2, true, h->bwd_cols / 4);
-            else HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_main, 0)); // step 1 publishes nothing
-            gemm_slice(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->slabs_dU, kchunk, z, h->st2);
-        }
-        gemm_fold(h->slabs_dU, nz, G4, N, h->dP + h->pl.U, G4, h->st2);
-        dW_sums(h->DG + (size_t)G4 * B, T, G4, h->dP + h->pl.W, h->dP + h->pl.b, h->dw_scratch, h->st2);
-        HIP_TRY(hipEventRecord(h->ev_join, h->st2));
-        HIP_TRY(hipStreamWaitEvent(h->st, h->ev_join, 0));
-        return 0;
-    }
-    if (h->persistent) {
-        if (h->bf16)
+        if (h->bf16) {
             RUN(K_BWD_PERSIST, bwd_persistent(reinterpret_cast<const float4 *>(h->Ubwd16), h->DG, h->DHy, h->G, h->C, h->H,
                                               h->xi, fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp,
                                               h->bwd_epoch, N, S, B, 8, h->st, nullptr, h->DGb));
-        else
-        RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd4 ? h->Ubwd4 : h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr,
-                                          h->P + h->pl.Why, dY, cb, h->abortp, h->bwd_epoch, N, S, B, h->bwd_cols, h->st,
-                                          h->stamps ? h->stamps + (size_t)2 * S * 8 : nullptr));
+        } else {
+            RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd4 ? h->Ubwd4 : h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi,
+                                              fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp, h->bwd_epoch, N, S,
+                                              B, h->bwd_cols, h->st, h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr, nullptr,
+                                              h->DGx, h->ring_base_b));
+            if (h->DGx) h->ring_base_b = bwd_ring_advance(h->ring_base_b, S);
+        }
     } else {
         HIP_TRY(hipMemsetAsync(h->dcnext, 0, sizeof(float) * N * B, h->st)); // R/lstm.cc:216-217
         for (int t = S - 1; t >= 1; t--) {
@@ -399,9 +318,6 @@ int do_backward(lstm_hip_ctx *h) {
     if (!fused)
         RUN(K_GEMM_DWHY, gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256,
                               h->splits_dWhy, h->slabs, h->st));
-    // dU = DG * H[0..S-2]^T            R/lstm.cc:250
-    RUN(K_GEMM_DU, gemm(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->dP + h->pl.U, G4, h->splits_dU,
-                        h->slabs_dU, h->st));
     // dW, db                           R/lstm.cc:251-252
     if (fused) { // accumulated per column group inside the recurrence: fold the groups in order
         const int NGb = (B + h->bwd_cols - 1) / h->bwd_cols;
@@ -413,12 +329,44 @@ int do_backward(lstm_hip_ctx *h) {
     } else {
         RUN(K_DW_DB, dW_db(h->DG + (size_t)G4 * B, h->xi + B, T, G4, h->dP + h->pl.W, h->dP + h->pl.b, h->dw_scratch, h->st));
     }
+    // Everything but dU is final here.  Inside the device-resident loop their all-reduce starts now, on st2, beside the dU
+    // product: ranges [dW] and [db | dWhy | dby] of the flat block (one group).  The dU range follows on `st` behind the
+    // product, ordered after ev_join, so the communicator never runs two collectives at once (do_allreduce).
+    if (h->comm && h->in_loop && !h->profiling) {
+        HIP_TRY(hipEventRecord(h->ev_fork, h->st));
+        HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+        int rc = 0;
+        if (g_rccl.GroupStart && g_rccl.GroupEnd) g_rccl.GroupStart();
+        rc = g_rccl.AllReduce(h->dP, h->dP, h->pl.U, /*ncclFloat*/ 7, /*ncclSum*/ 0, h->comm, h->st2);
+        if (rc == 0)
+            rc = g_rccl.AllReduce(h->dP + h->pl.b, h->dP + h->pl.b, h->pl.total - h->pl.b, 7, 0, h->comm, h->st2);
+        if (g_rccl.GroupStart && g_rccl.GroupEnd) {
+            const int rc2 = g_rccl.GroupEnd();
+            if (rc == 0) rc = rc2;
+        }
+        if (rc != 0)
+            return fail(LSTM_HIP_ERCCL, "ncclAllReduce (early ranges): %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+        HIP_TRY(hipEventRecord(h->ev_join, h->st2));
+        h->early_reduced = true;
+    }
+    // dU = DG * H[0..S-2]^T            R/lstm.cc:250
+    RUN(K_GEMM_DU, gemm(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->dP + h->pl.U, G4, h->splits_dU,
+                        h->slabs_dU, h->st));
     return 0;
 }
 
+// SUM all-reduce of the flat gradient block [dW | dU | db | dWhy | dby] over the ranks (SUM, not mean: the reference's
+// weight gradients are sums over batch columns, OV/lstm_eigen_opt/lstm.cc:271,297-299).  When do_backward has already
+// started the ranges that were final before the dU product (early_reduced), only dU is left: it goes on `st` behind the
+// product and behind ev_join, i.e. after the early ranges have finished on st2.
 int do_allreduce(lstm_hip_ctx *h) {
     if (!h->comm) return 0;
     int rc = 0;
+    if (h->early_reduced) {
+        h->early_reduced = false;
+        HIP_TRY(hipStreamWaitEvent(h->st, h->ev_join, 0));
+        RUN(K_ALLREDUCE, rc = g_rccl.AllReduce(h->dP + h->pl.U, h->dP + h->pl.U, h->pl.b - h->pl.U, 7, 0, h->comm, h->st));
+    } else
     RUN(K_ALLREDUCE, rc = g_rccl.AllReduce(h->dP, h->dP, h->pl.total, /*ncclFloat*/ 7, /*ncclSum*/ 0, h->comm, h->st));
     if (rc != 0)
         return fail(LSTM_HIP_ERCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
@@ -434,6 +382,8 @@ int do_adagrad(lstm_hip_ctx *h, double lr) {
 }
 
 } // namespace
+
+static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDeviceProp_t &prop);
 
 extern "C" {
 
@@ -465,8 +415,33 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(LSTM_HIP_ENODEV, "device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName);
     HIP_TRY(hipSetDevice(cfg->device));
+    // everything that can be refused is refused before the first allocation
+    const bool want_persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) &&
+                                 persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount, !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512);
+    if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) {
+        if (!want_persistent || cfg->N % 128 != 0 || cfg->N > 1024)
+            return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE needs the persistent engine and N a multiple of 128, <= 1024 (N=%d, B=%d)", cfg->N, cfg->B);
+        if (!persistent_supported_bf16(cfg->N, cfg->B, prop.multiProcessorCount, !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512))
+            return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE: the bf16 recurrence grids for N=%d, B=%d are not co-resident on %d CUs "
+                                         "(8-column groups: N/16 * ceil(B/8) workgroups)", cfg->N, cfg->B, prop.multiProcessorCount);
+    }
 
     lstm_hip_ctx *h = new lstm_hip_ctx();
+    const int rc = create_body(h, cfg, prop);
+    if (rc != 0) {
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep)); // destroy must not overwrite the reason
+        (void)lstm_hip_destroy(h);         // frees whatever had been allocated (every member is null-checked)
+        memcpy(g_err, keep, sizeof(keep));
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+} // extern "C"
+
+static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDeviceProp_t &prop) {
     h->cfg = *cfg;
     h->pl = ParamLayout::make(cfg->N, cfg->M);
     const size_t N = cfg->N, B = cfg->B, S = cfg->S, G4 = 4 * N;
@@ -492,14 +467,8 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
     ALLOC(h->dby_part, (size_t)256 * softmax_parts(h->T));
     h->splits_dWhy = gemm_pick_splits(256, (int)N, h->T);
     h->splits_dU = gemm_pick_splits((int)G4, (int)N, h->T);
-    h->chunk_steps = (int)((S - 1 + 8) / 9); // ~9 follower chunks per window
-    if (const char *e = getenv("LSTM_HIP_CHUNK_STEPS")) h->chunk_steps = atoi(e) > 0 ? atoi(e) : h->chunk_steps;
-    {
-        const size_t nz = (S - 1 + h->chunk_steps - 1) / h->chunk_steps;
-        const size_t want = nz > (size_t)h->splits_dU ? nz : (size_t)h->splits_dU;
-        ALLOC(h->slabs, (size_t)h->splits_dWhy * 256 * N);
-        ALLOC(h->slabs_dU, want * G4 * N);
-    }
+    ALLOC(h->slabs, (size_t)h->splits_dWhy * 256 * N);
+    ALLOC(h->slabs_dU, (size_t)h->splits_dU * G4 * N);
     ALLOC(h->dw_scratch, dW_scratch_bytes(h->T, (int)G4));
     ALLOC(h->xi, S * B);
     ALLOC(h->ti, S * B);
@@ -515,11 +484,11 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
     h->cnt_bytes = persistent_counter_bytes((int)S, (int)B);
     ALLOC(h->cnt, 2 * h->cnt_bytes / sizeof(unsigned));
     ALLOC(h->abortp, 4);
-    h->persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) && persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount);
+    const bool want_fused = !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512; // larger N: one workgroup per CU no longer holds
+    h->persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) &&                          // the dW table beside the weights
+                    persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount, want_fused);
     h->bwd_cols = bwd_group_cols(cfg->N, cfg->B, prop.multiProcessorCount);
-    if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) {
-        if (!h->persistent || cfg->N % 128 != 0 || (cfg->flags & LSTM_HIP_GRANULE_HANDOFF) || cfg->N > 1024)
-            return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE needs the persistent engine and N a multiple of 128, <= 1024 (N=%d, B=%d)", cfg->N, cfg->B);
+    if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) { // refusals: lstm_hip_create, before anything is allocated
         h->bf16 = true;
         h->bwd_cols = 8;
         ALLOC(h->Hb, S * B * N);
@@ -527,60 +496,49 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
         HIP_TRY(hipMalloc(&h->Ufwd16, (size_t)8 * N * N));
         HIP_TRY(hipMalloc(&h->Ubwd16, (size_t)8 * N * N));
     }
-    if (h->persistent && bwd_uses_m4((int)N, h->bwd_cols, h->bf16)) ALLOC(h->Ubwd4, N * N);
-    if (h->persistent && !h->bf16 && !(cfg->flags & (LSTM_HIP_GRANULE_HANDOFF | LSTM_HIP_DEBUG_STAMPS)) &&
-        fwd_uses_third_form((int)N, (int)B, prop.multiProcessorCount))
-    {
-        ALLOC(h->Ufwd4, N * N);
-        const char *e = getenv("LSTM_HIP_FWD_FORM"); // 3: counter hand-off (third form); default: data-as-flag (fourth)
-        if (!(e && atoi(e) == 3)) {
-            ALLOC(h->Hx, fwd_ring_floats((int)N, (int)B));
-            HIP_TRY(hipMemset(h->Hx, 0xff, sizeof(float) * fwd_ring_floats((int)N, (int)B)));
-            h->poll_cfg = getenv("LSTM_HIP_FWD_POLL") ? atoi(getenv("LSTM_HIP_FWD_POLL")) : 1;
+    if (h->persistent && bwd_uses_m4((int)N, h->bwd_cols, h->bf16)) {
+        ALLOC(h->Ubwd4, N * N);
+        // hand-off of the backward recurrence: sharded counters (default) or the data-as-flag ring ("flag"); read per handle
+        const char *e = getenv("LSTM_HIP_BWD_HANDOFF");
+        if (e && e[0] == 'f') {
+            ALLOC(h->DGx, bwd_ring_floats((int)N, (int)B));
+            HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * bwd_ring_floats((int)N, (int)B)));
         }
     }
-    if (h->persistent && !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512) // larger N: the dU tiles no longer fit the VGPRs
+    if (h->persistent && !h->bf16 && fwd_uses_8col_form((int)N, (int)B, prop.multiProcessorCount)) {
+        ALLOC(h->Ufwd4, N * N);
+        ALLOC(h->Hx, fwd_ring_floats((int)N, (int)B));
+        HIP_TRY(hipMemset(h->Hx, 0xff, sizeof(float) * fwd_ring_floats((int)N, (int)B)));
+        h->poll_cfg = getenv("LSTM_HIP_FWD_POLL") ? atoi(getenv("LSTM_HIP_FWD_POLL")) : 1; // tuning knob (flat from 0 to 4)
+    }
+    if (h->persistent && want_fused && h->bwd_cols == 8)
         ALLOC(h->gpart, (size_t)((B + h->bwd_cols - 1) / h->bwd_cols) * bwd_partial_floats(cfg->N));
-    // followers need whole MFMA k-tiles and whole softmax waves per time chunk
-    h->overlap = h->persistent && !(cfg->flags & (LSTM_HIP_NO_OVERLAP | LSTM_HIP_GRANULE_HANDOFF | LSTM_HIP_BF16_RECURRENCE)) && cfg->B % 16 == 0;
-    if (const char *e = getenv("LSTM_HIP_OVERLAP_MASK")) h->overlap_mask = atoi(e);
-    if (h->Ufwd4) h->overlap_mask &= ~1; // the forward followers count arrivals per 16-column group
-    if (h->overlap && (h->overlap_mask & 4)) {
-        // CU-partitioned overlap: the backward recurrence (N/16 * ceil(B/16) workgroups, one per CU) gets the
-        // even CUs, its followers the odd ones, so they do not compete for SIMD issue slots or LDS.
-        const int words = (prop.multiProcessorCount + 31) / 32;
-        std::vector<uint32_t> even(words, 0x55555555u), odd(words, 0xaaaaaaaau);
-        HIP_TRY(hipExtStreamCreateWithCUMask(&h->st_b, words, even.data()));
-        HIP_TRY(hipExtStreamCreateWithCUMask(&h->st2, words, odd.data()));
-    } else
     HIP_TRY(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    if (h->persistent && (cfg->flags & LSTM_HIP_GRANULE_HANDOFF)) ALLOC(h->Hg, S * B * N);
-    if (h->persistent && (cfg->flags & LSTM_HIP_DEBUG_STAMPS)) ALLOC(h->stamps, 4 * S * 8);
+    if (h->persistent && (cfg->flags & LSTM_HIP_DEBUG_STAMPS) && cfg->N == 512 && h->Hx && h->Ubwd4) ALLOC(h->stamps, 4 * S * 16);
     HIP_TRY(hipDeviceSynchronize());
-    *out = h;
     return 0;
 }
+
+extern "C" {
 
 int lstm_hip_destroy(lstm_hip_t *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
     if (h->eval_h) (void)lstm_hip_destroy(h->eval_h);
-    (void)hipStreamSynchronize(h->st);
+    if (h->st) (void)hipStreamSynchronize(h->st);
     if (h->st2) (void)hipStreamSynchronize(h->st2);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-    void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->Ubwd4, h->Ufwd4, h->Hx, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
-                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->Hg, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
+    void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->Ubwd4, h->Ufwd4, h->Hx, h->DGx, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
+                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    for (hipEvent_t e : {h->ev_fork, h->ev_main, h->ev_join})
+    for (hipEvent_t e : {h->ev_fork, h->ev_join})
         if (e) (void)hipEventDestroy(e);
     if (h->st2) (void)hipStreamDestroy(h->st2);
-    if (h->st_b) (void)hipStreamDestroy(h->st_b);
     if (h->st) (void)hipStreamDestroy(h->st);
     delete h;
     return 0;
@@ -647,6 +605,32 @@ int lstm_hip_set_window(lstm_hip_t *h, const int32_t *xi, const int32_t *ti) {
     HIP_TRY(hipMemcpyAsync(h->Tr, ti, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->st));
     HIP_TRY(hipMemsetAsync(h->head, 0, sizeof(int32_t), h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
+    return 0;
+}
+int lstm_hip_set_inputs_dense(lstm_hip_t *h, const float *h0, const float *c0, const float *x, const float *target) {
+    CHECK(h);
+    if (!x || !target) return fail(LSTM_HIP_EINVAL, "set_inputs_dense: null x or target");
+    const size_t cols = (size_t)h->cfg.S * h->cfg.B;
+    std::vector<int32_t> xi(cols), ti(cols);
+    for (int which = 0; which < 2; which++) {
+        const float *m = which ? target : x;
+        std::vector<int32_t> &out = which ? ti : xi;
+        for (size_t c = 0; c < cols; c++) {
+            int32_t idx = -1;
+            for (int r = 0; r < LSTM_HIP_VOCAB; r++) {
+                const float v = m[c * LSTM_HIP_VOCAB + r];
+                if (v == 0.0f) continue;
+                if (v != 1.0f || idx >= 0)
+                    return fail(LSTM_HIP_EINVAL, "set_inputs_dense: column %zu of %s is not one-hot (row %d holds %g)", c,
+                                which ? "target" : "x", r, (double)v);
+                idx = r;
+            }
+            out[c] = idx;
+        }
+    }
+    int rc = lstm_hip_set_window(h, xi.data(), ti.data());
+    if (rc) return rc;
+    if (h0 || c0) return lstm_hip_set_state(h, 0, h0, c0);
     return 0;
 }
 int lstm_hip_get_window(lstm_hip_t *h, int32_t *xi, int32_t *ti) {
@@ -798,6 +782,16 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, h->st));
     }
+    h->in_loop = true;
+    struct LoopGuard { // leaves the loop state clean on every return path
+        lstm_hip_ctx *h;
+        hipEvent_t &a, &b;
+        ~LoopGuard() {
+            h->in_loop = false;
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } guard{h, e0, e1};
     for (int64_t i = 0; i < count; i++) {
         RUN(K_SLIDE, slide_window(h->text, h->text_len, h->pos, h->Xr, h->Tr, h->head, h->xi, h->ti, h->H, h->C,
                                   h->cfg.S, h->cfg.B, h->cfg.N, h->stride, h->carry_col, h->st));
@@ -814,8 +808,6 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
         HIP_TRY(hipEventRecord(e1, h->st));
         HIP_TRY(hipEventSynchronize(e1));
         HIP_TRY(hipEventElapsedTime(elapsed_ms, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
     }
     if (losses && count > 0)
         HIP_TRY(hipMemcpyAsync(losses, h->d_losses, sizeof(double) * count, hipMemcpyDeviceToHost, h->st));
@@ -844,13 +836,18 @@ int lstm_hip_eval_bits(lstm_hip_t *h, const uint8_t *text, size_t len, double *b
     const int N = h->cfg.N;
     if (!h->persistent || (h->cfg.flags & LSTM_HIP_STEP_KERNELS)) {
         uint8_t *d_text = nullptr;
+        struct Free {
+            uint8_t *&p;
+            ~Free() {
+                if (p) (void)hipFree(p);
+            }
+        } free_text{d_text};
         HIP_TRY(hipMalloc((void **)&d_text, len));
         HIP_TRY(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, h->st));
         eval_bits(h->P, N, d_text, len, h->d_loss, nullptr, h->st);
         double sum = 0.0;
         HIP_TRY(hipMemcpyAsync(&sum, h->d_loss, sizeof(double), hipMemcpyDeviceToHost, h->st));
         HIP_TRY(hipStreamSynchronize(h->st));
-        HIP_TRY(hipFree(d_text));
         *bits_per_char = sum / (double)(len - 1);
         return 0;
     }
@@ -897,6 +894,16 @@ int lstm_hip_sample(lstm_hip_t *h, float *h0, float *c0, const double *u, int32_
     float *d_hc = nullptr;
     double *d_u = nullptr;
     uint8_t *d_out = nullptr;
+    struct Scratch { // released on every return path
+        float *&a;
+        double *&b;
+        uint8_t *&c;
+        ~Scratch() {
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
+            if (c) (void)hipFree(c);
+        }
+    } scratch{d_hc, d_u, d_out};
     HIP_TRY(hipMalloc((void **)&d_hc, sizeof(float) * 2 * N));
     HIP_TRY(hipMalloc((void **)&d_u, sizeof(double) * (count + 1)));
     HIP_TRY(hipMalloc((void **)&d_out, (size_t)count + 1));
@@ -935,16 +942,13 @@ int lstm_hip_sample(lstm_hip_t *h, float *h0, float *c0, const double *u, int32_
     HIP_TRY(hipMemcpyAsync(c0, d_hc + N, sizeof(float) * N, hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipMemcpyAsync(out, d_out, count, hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
-    (void)hipFree(d_hc);
-    (void)hipFree(d_u);
-    (void)hipFree(d_out);
     return 0;
 }
 
 int lstm_hip_debug_stamps(lstm_hip_t *h, uint64_t *out, size_t count) {
     CHECK(h);
-    if (!h->stamps) return fail(LSTM_HIP_ESTATE, "handle was not created with LSTM_HIP_DEBUG_STAMPS on a supported shape");
-    const size_t have = (size_t)4 * h->cfg.S * 8;
+    if (!h->stamps) return fail(LSTM_HIP_ESTATE, "handle was not created with LSTM_HIP_DEBUG_STAMPS at hidden 512 on the 8-column forms");
+    const size_t have = (size_t)4 * h->cfg.S * 16;
     HIP_TRY(hipMemcpyAsync(out, h->stamps, sizeof(uint64_t) * (count < have ? count : have), hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
     return 0;

@@ -127,10 +127,8 @@ __device__ __forceinline__ void st_sc1(float4 f, __amdgpu_buffer_rsrc_t r, int b
 #define POLL_SLEEP 1
 #endif
 template <int CNT_SH>
-__device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, unsigned epoch, unsigned *abortp, int lane,
-                                              int first_delay = 0) {
+__device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, unsigned epoch, unsigned *abortp, int lane) {
     const unsigned expect = lane < CNT_SH ? epoch * (unsigned)((n_prod - lane + CNT_SH - 1) / CNT_SH) : 0u;
-    for (int i = 0; i < first_delay; i++) __builtin_amdgcn_s_sleep(1); // 64 cycles each
     for (int spins = 0;; spins++) {
         unsigned v = 0;
         if (lane < CNT_SH) v = __hip_atomic_load(cp + lane * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -146,17 +144,11 @@ __device__ __forceinline__ bool wait_arrivals(const unsigned *cp, int n_prod, un
 // ------------------------------------------------------------------------------------------------
 // forward recurrence, t = 1..S-1, N = 64*NK4W.  grid (N/4, ceil(B/16)), 256 threads.
 // ------------------------------------------------------------------------------------------------
-// STAMP builds record s_memtime at five points of every step for two workgroups (diagnostics only:
-// the stamps go to a buffer nothing else reads; the shipped path is the STAMP=false instantiation).
-#define STAMP_AT(k)                                                                      \
-    if (STAMP && l == 0 && w == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
-        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 8 + (k)] = __builtin_amdgcn_s_memtime();
-template <int NK4W, bool FAST, bool STAMP = false>
+template <int NK4W, bool FAST>
 __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict__ Ufwd, const float *__restrict__ W,
                                                         const float *__restrict__ bias, float *H, float *__restrict__ C,
                                                         float *__restrict__ G, const int32_t *__restrict__ xi,
-                                                        unsigned *cnt, unsigned *abortp, unsigned epoch, int S, int B,
-                                                        int stagger, unsigned long long *stamps = nullptr) {
+                                                        unsigned *cnt, unsigned *abortp, unsigned epoch, int S, int B) {
     constexpr int N = 64 * NK4W, G4 = 4 * N, nk4 = N / 16;
     __shared__ float red[4 * 4 * 64];
     __shared__ int s_abort;
@@ -180,15 +172,8 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
     const __amdgpu_buffer_rsrc_t rH = make_rsrc(H, (size_t)S * N * B * sizeof(float));
     if (threadIdx.x == 0) s_abort = 0;
     __syncthreads();
-    // Stagger the column groups in time: their recurrences are independent, and every step of a
-    // group is a burst of device-scope loads (all its workgroups pull the same h_{t-1}); offsetting
-    // group g by g/NG of a step keeps the groups out of each other's burst.
-    if (!STAMP)
-        for (int i = 0; i < g * (stagger & 255); i++) __builtin_amdgcn_s_sleep(32);
-
     for (int t = 1; t < S; t++) {
         float wx[4] = {0.f, 0.f, 0.f, 0.f};
-        STAMP_AT(0)
         if (w == 0) {
             const int x = xi[t * B + colc];
             if (x >= 0) {
@@ -197,26 +182,24 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
             }
             if (t > 1) {
                 const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
-                if (!wait_arrivals<FWD_SH>(cp, NB, epoch, abortp, l, stagger >> 8) && l == 0) s_abort = 1;
+                if (!wait_arrivals<FWD_SH>(cp, NB, epoch, abortp, l) && l == 0) s_abort = 1;
             }
         }
         __syncthreads();
         if (s_abort) return;
-        STAMP_AT(1)
 
         const int off = (int)((((size_t)(t - 1) * B + colc) * N + 16 * (w * NK4W) + 4 * q) * sizeof(float));
         // Software pipeline: PF fragment loads in flight ahead of the MFMAs (the scheduler alone keeps two;
-        // see k_bwd_persistent).  Diagnostic builds: `stagger` doubles as "fragments to load".
+        // see k_bwd_persistent).
         constexpr int PF = FWD_PF < NK4W ? FWD_PF : NK4W;
         float4 b[NK4W];
 #pragma unroll
-        for (int i = 0; i < PF; i++) b[i] = (STAMP && i >= stagger) ? float4{0.f, 0.f, 0.f, 0.f} : ld_sc1(rH, off + 64 * i);
+        for (int i = 0; i < PF; i++) b[i] = ld_sc1(rH, off + 64 * i);
         __builtin_amdgcn_sched_barrier(0);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < NK4W; i++) {
-            if (i + PF < NK4W)
-                b[i + PF] = (STAMP && i + PF >= stagger) ? float4{0.f, 0.f, 0.f, 0.f} : ld_sc1(rH, off + 64 * (i + PF));
+            if (i + PF < NK4W) b[i + PF] = ld_sc1(rH, off + 64 * (i + PF));
             if (i & 1) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc1, 0, 0, 0);
@@ -233,7 +216,6 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
 #pragma unroll
         for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
         __syncthreads();
-        STAMP_AT(2)
 
         if (w == 0) {
             float pre[4];
@@ -254,12 +236,10 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
             h4.y = __shfl(hv, 16 + c, 64);
             h4.z = __shfl(hv, 32 + c, 64);
             h4.w = __shfl(hv, 48 + c, 64);
-            STAMP_AT(3)
-            if (q == 0 && col < B) st_sc1(h4, rH, (int)((((size_t)t * B + col) * N + 4 * p) * sizeof(float)));
+                if (q == 0 && col < B) st_sc1(h4, rH, (int)((((size_t)t * B + col) * N + 4 * p) * sizeof(float)));
             if (t + 1 < S) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                STAMP_AT(4)
-                if (l == 0)
+                        if (l == 0)
                     __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * CNT_SLOTS + (p & (FWD_SH - 1))) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -399,184 +379,24 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2(const float4 *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward recurrence, third form: grid (N/16, ceil(B/8)), 512 threads, the counterpart of the backward kernel's 4x4x1
-// form.  A workgroup owns 16 units (64 gate rows) for a group of EIGHT batch columns, so a column group is N/16 = 32
-// workgroups at N = 512: one XCD's worth, which (checked every launch, see k_bwd_persistent) lets h_t be published
-// with plain stores that stay in the XCD's L2.  8-column groups on 16x16x4 tiles would waste half the matrix pipe;
-// v_mfma_f32_4x4x1 with operand broadcast does not: block = 8x + u (lane = 4*block + i, u = 0..7) computes
+// forward recurrence, 8-column form (the default at B > 8): grid (N/16, ceil(B/8)), 512 threads, one workgroup per CU.
+// A workgroup owns 16 units (64 gate rows) for a group of EIGHT batch columns, so a column group is N/16 = 32 workgroups
+// at N = 512: one XCD's worth.  8-column groups on 16x16x4 tiles would waste half the matrix pipe; v_mfma_f32_4x4x1 with
+// operand broadcast does not: block = 8x + u (lane = 4*block + i, u = 0..7) computes
 //   D[i][j] += h[k][column 4x+i] * U[gate j of unit 8*pass + u][k]                 (pass = 0, 1)
 // CBSZ = 3 / ABID = s makes all eight u-blocks of a half read h from slot s of the loaded register (one register = 8
 // values of k x 8 columns = 8 instructions), BLGP = 1 / 2 makes both x-halves read the weights from one half of the
 // weight register (2 values of k each).  Every lane carries data and no partial sums need folding across lanes.  K is
 // split over the 8 waves; waves 0 and 1 finish the 128 (unit, column) pairs.  N = 256*NKQ, weights Ufwd4 (k_pack_U).
-// ------------------------------------------------------------------------------------------------
-template <int NKQ, bool FAST>
-__global__ __launch_bounds__(512) void k_fwd_persistent3(const float4 *__restrict__ Ufwd4, const float *__restrict__ W,
-                                                         const float *__restrict__ bias, float *H, float *__restrict__ C,
-                                                         float *__restrict__ G, const int32_t *__restrict__ xi,
-                                                         unsigned *cnt, unsigned *abortp, unsigned epoch, int S, int B) {
-    constexpr int N = 256 * NKQ, G4 = 4 * N, Kw = N / 8, NL = Kw / 32, RS = 136;
-    __shared__ float red[8 * 4 * RS]; // [wave][gate][column*16 + unit], rows padded (bank spread of the writes)
-    __shared__ int s_abort, s_local;
-    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int NB3 = gridDim.x, NG = gridDim.y;
-    const int lin_ = blockIdx.x + NB3 * blockIdx.y;
-    const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
-    // MFMA role: lane = 32x + 4u + i
-    const int lx = l >> 5, lu = (l >> 2) & 7, li = l & 3;
-    const int mcol = 8 * g + 4 * lx + li, mcolc = mcol < B ? mcol : B - 1;
-    // gating role (waves 0, 1): tid = column*16 + unit
-    const int gc = (tid >> 4) & 7, gu = tid & 15;
-    const int col = 8 * g + gc, colc = col < B ? col : B - 1;
-    const int j = 16 * kb + gu;
-
-    float4 wq[2][NL][2][2]; // [pass][L][k-pair half][slot half], components: slot & 3
-#pragma unroll
-    for (int ps = 0; ps < 2; ps++)
-#pragma unroll
-        for (int L = 0; L < NL; L++)
-#pragma unroll
-            for (int eh = 0; eh < 2; eh++)
-#pragma unroll
-                for (int sh = 0; sh < 2; sh++)
-                    wq[ps][L][eh][sh] = Ufwd4[(((((((size_t)kb * 8 + w) * 2 + ps) * NL + L) * 2 + eh) * 2 + sh) * 64) + l];
-    float bs[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
-    if (w < 2) {
-#pragma unroll
-        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
-        cprev = C[(size_t)colc * N + j];
-    }
-    const __amdgpu_buffer_rsrc_t rH = make_rsrc(H, (size_t)S * N * B * sizeof(float));
-    if (tid == 0) {
-        s_abort = 0;
-        s_local = 0;
-    }
-    // XCD-local hand-off, verified per launch exactly as in k_bwd_persistent (step-0 counter slots of the group)
-    unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
-    if (XCD_LOCAL && tid == 0)
-        __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    bool local_pub = false;
-    __syncthreads();
-
-    for (int t = 1; t < S; t++) {
-        float wx[4] = {0.f, 0.f, 0.f, 0.f};
-        if (w < 2) {
-            const int x = xi[t * B + colc];
-            if (x >= 0) {
-#pragma unroll
-                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
-            }
-        }
-        if (w == 0 && t > 1) {
-            const unsigned *cp = cnt + (size_t)((t - 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
-            if (!wait_arrivals<FWD_SH>(cp, 2 * NB3, epoch, abortp, l) && l == 0) s_abort = 1;
-            if (XCD_LOCAL && t == 2) { // every workgroup of the group has published its XCC id by now
-                bool same = true;
-                unsigned mine = 0;
-                for (int i = l; i < NB3; i += 64) {
-                    const unsigned v = __hip_atomic_load(xcc_tab + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    mine = v;
-                    same = same && (v >> 4) == epoch;
-                }
-                const unsigned first = __builtin_amdgcn_readfirstlane(mine);
-                for (int i = l; i < NB3; i += 64) same = same && mine == first;
-                if (NB3 > 64) same = false;
-                if ((XCD_FORCE_LOCAL || __all(same)) && l == 0) s_local = 1;
-            }
-        }
-        __syncthreads();
-        if (s_abort) return;
-        if (XCD_LOCAL && t == 2) local_pub = s_local != 0;
-
-        const int off = (int)((((size_t)(t - 1) * B + mcolc) * N + Kw * w + 4 * lu) * sizeof(float));
-        float4 b[NL];
-#pragma unroll
-        for (int i = 0; i < NL; i++) b[i] = ld_sc1(rH, off + 128 * i);
-        // four independent accumulation chains: [pass][slot parity]
-        f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
-#define F3_HALF(av, q0, q1, s0, blgp)                                                   \
-    c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.x, c00, 3, s0 + 0, blgp);          \
-    c10 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.x, c10, 3, s0 + 0, blgp);          \
-    c01 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.y, c01, 3, s0 + 1, blgp);          \
-    c11 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.y, c11, 3, s0 + 1, blgp);          \
-    c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.z, c00, 3, s0 + 2, blgp);          \
-    c10 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.z, c10, 3, s0 + 2, blgp);          \
-    c01 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.w, c01, 3, s0 + 3, blgp);          \
-    c11 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.w, c11, 3, s0 + 3, blgp);
-#define F3_STEP(av, L, eh, blgp)                             \
-    F3_HALF(av, wq[0][L][eh][0], wq[1][L][eh][0], 0, blgp)   \
-    F3_HALF(av, wq[0][L][eh][1], wq[1][L][eh][1], 4, blgp)
-#pragma unroll
-        for (int i = 0; i < NL; i++) {
-            F3_STEP(b[i].x, i, 0, 1)
-            F3_STEP(b[i].y, i, 0, 2)
-            F3_STEP(b[i].z, i, 1, 1)
-            F3_STEP(b[i].w, i, 1, 2)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef F3_STEP
-#undef F3_HALF
-        // lane (x, u, j), reg r of pass ps holds gate j of unit 8*ps + u for column 4x + r: leave it where the gating
-        // thread (column*16 + unit) reads consecutive addresses
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            red[(w * 4 + li) * RS + (4 * lx + r) * 16 + lu] = c00[r] + c01[r];
-            red[(w * 4 + li) * RS + (4 * lx + r) * 16 + 8 + lu] = c10[r] + c11[r];
-        }
-        __syncthreads();
-
-        if (w < 2) {
-            float pre[4];
-#pragma unroll
-            for (int gt = 0; gt < 4; gt++) {
-                float uh = red[(0 * 4 + gt) * RS + tid];
-#pragma unroll
-                for (int ww = 1; ww < 8; ww++) uh += red[(ww * 4 + gt) * RS + tid];
-                pre[gt] = (wx[gt] + uh) + bs[gt]; // R/lstm.cc:176
-            }
-            const float ig = p_sigm<FAST>(pre[0]), og = p_sigm<FAST>(pre[1]), fg = p_sigm<FAST>(pre[2]); // :179
-            const float ug_ = p_tanh<FAST>(pre[3]);                                                       // :182
-            const float cv = p_tanh<FAST>(ig * ug_ + fg * cprev);                                         // :185-189
-            const float hv = og * cv;                                                                     // :192
-            cprev = cv;
-            // four consecutive units sit in the four lanes of a quad: gather them for one 16-byte store
-            float4 h4;
-            h4.x = dpp_f<0x00>(hv); // quad_perm [0,0,0,0]
-            h4.y = dpp_f<0x55>(hv); // [1,1,1,1]
-            h4.z = dpp_f<0xAA>(hv); // [2,2,2,2]
-            h4.w = dpp_f<0xFF>(hv); // [3,3,3,3]
-            if ((gu & 3) == 0 && col < B) {
-                if (XCD_LOCAL && local_pub) *reinterpret_cast<float4 *>(H + ((size_t)t * B + col) * N + j) = h4;
-                else st_sc1(h4, rH, (int)((((size_t)t * B + col) * N + j) * sizeof(float)));
-            }
-            if (t + 1 < S) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (l == 0)
-                    __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * CNT_SLOTS + ((2 * kb + w) & (FWD_SH - 1))) * CNT_STRIDE, 1u,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (col < B) {
-                float *gcp = G + ((size_t)t * B + col) * G4 + j;
-                gcp[0] = ig;
-                gcp[N] = og;
-                gcp[2 * N] = fg;
-                gcp[3 * N] = ug_;
-                C[((size_t)t * B + col) * N + j] = cv;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward recurrence, fourth form: the decomposition and arithmetic of the third form, but the hand-off carries no
-// counter, no drain and no poll -> barrier -> load sequence: THE DATA IS THE FLAG (Guideline 16, recipe R2, with the
-// tag folded into the value space).  h_t is published into a ring of HX_RING = 4 step slots Hx[slot][B][N] whose
-// words hold the sentinel 0xFFFFFFFF (a NaN pattern no computed h can have; a NaN input with that payload is
+//
+// Hand-off: THE DATA IS THE FLAG (Guideline 16, recipe R2, with the tag folded into the value space) -- no counter, no
+// drain, no poll -> barrier -> load sequence.  h_t is published into a ring of HX_RING = 4 step slots Hx[slot][B][N]
+// whose words hold the sentinel 0xFFFFFFFF (a NaN pattern no computed h can have; a NaN input with that payload is
 // canonicalised on the way in) until the producer overwrites them, each word exactly once per use of the slot.  A
 // consuming WAVE re-issues the sc1 loads of its own K-slice -- the loads it needs anyway -- until no word is the
 // sentinel, then goes straight to its MFMAs: per step one store -> L2 -> load hop instead of store, drain, atomic,
-// poll, barrier, load.  Torn 16-byte stores cannot matter: every dword is checked by the lane that consumes it.
+// poll, barrier, load (measured against that counter protocol on the same decomposition: 312 -> 259 us, bit-identical).
+// Torn 16-byte stores cannot matter: every dword is checked by the lane that consumes it.
 //
 // Slot reuse.  Step t reads slot(t-1), publishes into slot(t) and, right after publishing, resets its own words of
 // slot(t+2) to the sentinel (slot(s) = (s + ring_base) & 3).  Safe because
@@ -589,7 +409,17 @@ __global__ __launch_bounds__(512) void k_fwd_persistent3(const float4 *__restric
 // that these are its slots 1 and 2 (the two that no in-launch reset precedes).  The host fills the ring with the
 // sentinel once (and after an abort).  Step 1 reads the carry column H[0], written before the launch.
 // The time-batched products read the plain H, stored off the chain.  One workgroup barrier per step (the K-slice
-// reduction), `red` double-buffered by step parity.  XCD-local plain stores as in the third form (verified per launch).
+// reduction), `red` double-buffered by step parity.
+//
+// XCD-local publish (speed only, checked every launch): when all workgroups of a column group run on ONE XCD, h_t can be
+// published with plain stores -- the lines stay in that XCD's L2, which serves the group's sc1 loads directly -- instead
+// of sc1 write-through stores that every consumer pulls back over the fabric.  Placement is observed, not promised, so
+// each workgroup publishes its HW_REG_XCC_ID (sc1, drained before its first publish) in the step-0 counter slots of its
+// group; once h_1 of every member has arrived the gating waves read the table and take the plain-store path only if
+// all entries agree and were written in this launch.  (Control experiment: DESIGN.md.)
+//
+// STAMP builds (LSTM_HIP_DEBUG_STAMPS, N = 512) record s_memtime at the points marked FSTAMP for two workgroups; the
+// stamps go to a buffer nothing else reads and the shipped path is the STAMP = false instantiation.
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned HX_SENT = 0xFFFFFFFFu;
 constexpr int HX_RING = 4;
@@ -599,12 +429,19 @@ __device__ __forceinline__ bool hx_ready(const float4 &v) {
 }
 __device__ __forceinline__ float hx_canon(float v) { return __float_as_uint(v) == HX_SENT ? __uint_as_float(0x7FC00000u) : v; }
 
-template <int NKQ, bool FAST>
+// stamp slots [workgroup 0 | gridDim.x/2][t][16]: wave 0 (MFMA + gating) 0-7, wave 3 (MFMA only) 8-12
+#define FSTAMP(wave, k)                                                                                        \
+    if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
+        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = __builtin_amdgcn_s_memtime();
+#define FSTAMP_VAL(wave, k, v)                                                                                 \
+    if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
+        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = (unsigned long long)(v);
+template <int NKQ, bool FAST, bool STAMP = false>
 __global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restrict__ Ufwd4, const float *__restrict__ W,
                                                          const float *__restrict__ bias, float *H, float *__restrict__ C,
                                                          float *__restrict__ G, const int32_t *__restrict__ xi, float *Hx,
                                                          unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base,
-                                                         int S, int B, int poll_cfg) {
+                                                         int S, int B, int poll_cfg, unsigned long long *stamps = nullptr) {
     constexpr int N = 256 * NKQ, G4 = 4 * N, Kw = N / 8, NL = Kw / 32, RS = 136;
     __shared__ float red[2][8 * 4 * RS]; // [step parity][wave][gate][column*16 + unit]
     __shared__ int s_abort;
@@ -660,6 +497,8 @@ __global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restric
             }
         }
         float4 b[NL];
+        FSTAMP(0, 0) FSTAMP(3, 8)
+        int polls = 0;
         if (t == 1) {
             const int off = (int)((((size_t)mcolc) * N + Kw * w + 4 * lu) * sizeof(float));
 #pragma unroll
@@ -677,6 +516,7 @@ __global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restric
                     b[i] = ld_sc1(rHx, off + 128 * i);
                     good = good && hx_ready(b[i]);
                 }
+                if (STAMP) polls = spins + 1;
                 if (__all(good)) {
                     ok = true;
                     break;
@@ -689,6 +529,7 @@ __global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restric
                 s_abort = 1;
             }
         }
+        FSTAMP(0, 1) FSTAMP(3, 9) FSTAMP_VAL(0, 7, polls) FSTAMP_VAL(3, 12, polls)
         f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
 #define F4_HALF(av, q0, q1, s0, blgp)                                                   \
     c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.x, c00, 3, s0 + 0, blgp);          \
@@ -712,6 +553,7 @@ __global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restric
         }
 #undef F4_STEP
 #undef F4_HALF
+        FSTAMP(0, 2) FSTAMP(3, 10)
         float *rp = red[par];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -720,6 +562,7 @@ __global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restric
         }
         __syncthreads();
         if (s_abort) return;
+        FSTAMP(0, 3) FSTAMP(3, 11)
 
         if (w < 2) {
             if (XCD_LOCAL && t == 2) { // every workgroup of the group has published h_1, hence its XCC id before it
@@ -751,8 +594,10 @@ __global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restric
             h4.y = dpp_f<0x55>(hv);
             h4.z = dpp_f<0xAA>(hv);
             h4.w = dpp_f<0xFF>(hv);
+            FSTAMP(0, 4)
             // the reset this wave issued a step ago (and every older store) has completed before h_t can be seen
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FSTAMP(0, 5)
             if ((gu & 3) == 0 && col < B) {
                 const float4 hp = {hx_canon(h4.x), hx_canon(h4.y), hx_canon(h4.z), hx_canon(h4.w)};
                 const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
@@ -776,9 +621,12 @@ __global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restric
                 gcp[3 * N] = ug_;
                 C[((size_t)t * B + col) * N + j] = cv;
             }
+            FSTAMP(0, 6)
         }
     }
 }
+#undef FSTAMP
+#undef FSTAMP_VAL
 
 // ------------------------------------------------------------------------------------------------
 // bf16 recurrence (LSTM_HIP_BF16_RECURRENCE, BASELINE configs[4]): the operands of U*h_prev are bfloat16
@@ -1076,165 +924,21 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward recurrence, granule hand-off (LSTM_HIP_GRANULE_HANDOFF; measured slower).  Same decomposition and arithmetic as
-// k_fwd_persistent, but h_t travels as 8-byte {tag, value} granules (Guideline 16, recipe R2: the data
-// IS the flag): the producing lane writes ONE aligned 8-byte sc1 store per value and moves on -- no
-// drain, no counter, no flag -- and every consuming wave sweeps the granules of its own K-quarter
-// with 16-byte sc1 loads until every tag equals this step's epoch.  The epoch is
-// epoch_base + t with epoch_base = S * (window serial), so a tag left by an earlier window can never
-// match.  Step 1 reads the carry column from plain memory (it was written before the launch).
-// The plain H (which the time-batched products read) is still written, off the critical path.
-// ------------------------------------------------------------------------------------------------
-template <int NK4W, bool FAST>
-__global__ __launch_bounds__(256) void k_fwd_persistent_g(const float4 *__restrict__ Ufwd, const float *__restrict__ W,
-                                                          const float *__restrict__ bias, float *__restrict__ H,
-                                                          float *__restrict__ C, float *__restrict__ G,
-                                                          unsigned long long *Hg, const int32_t *__restrict__ xi,
-                                                          unsigned *abortp, unsigned epoch_base, int S, int B) {
-    constexpr int N = 64 * NK4W, G4 = 4 * N, nk4 = N / 16;
-    __shared__ float red[4 * 4 * 64];
-    __shared__ int s_abort;
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int p = blockIdx.x, g = blockIdx.y;
-    const int q = l >> 4, c = l & 15;
-    const int col = 16 * g + c, colc = col < B ? col : B - 1;
-    const int j = 4 * p + q;
-
-    float4 a[NK4W];
-#pragma unroll
-    for (int i = 0; i < NK4W; i++) a[i] = Ufwd[((size_t)p * nk4 + w * NK4W + i) * 64 + l];
-    float bs[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
-    if (w == 0) {
-#pragma unroll
-        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
-        cprev = C[(size_t)colc * N + j];
-    }
-    const __amdgpu_buffer_rsrc_t rG = make_rsrc(Hg, (size_t)S * N * B * 8);
-    if (threadIdx.x == 0) s_abort = 0;
-    __syncthreads();
-
-    for (int t = 1; t < S; t++) {
-        float wx[4] = {0.f, 0.f, 0.f, 0.f};
-        if (w == 0) {
-            const int x = xi[t * B + colc];
-            if (x >= 0) {
-#pragma unroll
-                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
-            }
-        }
-        float4 b[NK4W];
-        if (t == 1) {
-            const float *hp = H + (size_t)colc * N + 16 * (w * NK4W) + 4 * q;
-#pragma unroll
-            for (int i = 0; i < NK4W; i++) b[i] = *reinterpret_cast<const float4 *>(hp + 16 * i);
-        } else {
-            const unsigned want = epoch_base + (unsigned)(t - 1);
-            const int off = (int)((((size_t)(t - 1) * B + colc) * N + 16 * (w * NK4W) + 4 * q) * 8);
-            bool ok = false;
-            // phase 1: cheap poll -- only the first k-step of this wave's quarter (2 loads per lane,
-            // granules of 4 producers) until it carries this step's tag; a full 16 KB sweep per poll
-            // iteration by every wave of the chip starves the payload traffic it is waiting for
-            int spins = 0;
-            for (; spins <= SPIN_LIMIT; spins++) {
-                asm volatile("" ::: "memory");
-                const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rG, off, 0, 16);
-                const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rG, off + 16, 0, 16);
-                const bool good = v0.y == want && v0.w == want && v1.y == want && v1.w == want;
-                if (__all(good)) break;
-                if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                    spins = SPIN_LIMIT + 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            // phase 2: full sweep, every tag checked; repeated only if some producer is later than the polled ones
-            for (; spins <= SPIN_LIMIT; spins++) {
-                asm volatile("" ::: "memory"); // every sweep re-reads memory (no hoisting of the loads)
-                bool good = true;
-#pragma unroll
-                for (int i = 0; i < NK4W; i++) {
-                    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rG, off + 128 * i, 0, 16);
-                    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rG, off + 128 * i + 16, 0, 16);
-                    good = good && v0.y == want && v0.w == want && v1.y == want && v1.w == want;
-                    b[i].x = __uint_as_float(v0.x);
-                    b[i].y = __uint_as_float(v0.z);
-                    b[i].z = __uint_as_float(v1.x);
-                    b[i].w = __uint_as_float(v1.z);
-                }
-                if (__all(good)) {
-                    ok = true;
-                    break;
-                }
-                if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (!ok && l == 0) {
-                __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_abort = 1;
-            }
-        }
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < NK4W; i++) {
-            if (i & 1) {
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc1, 0, 0, 0);
-            } else {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc0, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
-        __syncthreads();
-        if (s_abort) return;
-
-        if (w == 0) {
-            float pre[4];
-#pragma unroll
-            for (int gt = 0; gt < 4; gt++) {
-                const float uh = ((red[(0 * 4 + gt) * 64 + l] + red[(1 * 4 + gt) * 64 + l]) + red[(2 * 4 + gt) * 64 + l]) +
-                                 red[(3 * 4 + gt) * 64 + l];
-                pre[gt] = (wx[gt] + uh) + bs[gt]; // R/lstm.cc:176
-            }
-            const float ig = p_sigm<FAST>(pre[0]), og = p_sigm<FAST>(pre[1]), fg = p_sigm<FAST>(pre[2]); // :179
-            const float ug = p_tanh<FAST>(pre[3]);                                                        // :182
-            const float cv = p_tanh<FAST>(ig * ug + fg * cprev);                                          // :185-189
-            const float hv = og * cv;                                                                     // :192
-            cprev = cv;
-            if (col < B) {
-                if (t + 1 < S) { // publish: ONE aligned 8-byte {value, tag} store, nothing to wait for
-                    const unsigned long long gran =
-                        ((unsigned long long)(epoch_base + (unsigned)t) << 32) | (unsigned long long)__float_as_uint(hv);
-                    __hip_atomic_store(Hg + ((size_t)t * B + col) * N + j, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                H[((size_t)t * B + col) * N + j] = hv;
-                float *gc = G + ((size_t)t * B + col) * G4 + j;
-                gc[0] = ig;
-                gc[N] = og;
-                gc[2 * N] = fg;
-                gc[3 * N] = ug;
-                C[((size_t)t * B + col) * N + j] = cv;
-            }
-        }
-        __syncthreads(); // red is rewritten by the next step
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // backward recurrence, t = S-1..1, N = 32*NR4W.  grid (N/16, ceil(B/COLS)), 512 threads.
 // Workgroup (kb, g) owns hidden units 16kb..16kb+15 for column group g (COLS = 8 or 16 batch columns): the tile
 // dhnext = U^T * dg[t+1] (R/lstm.cc:255) with K = 4N split over its 8 waves (U^T fragments in VGPRs) -- 16x16x4 MFMA
 // tiles, or for 8-column fp32 groups (M4) v_mfma_f32_4x4x1 blocks with operand broadcast, which leave no tile column
 // empty -- then one thread per (unit, column) does R/lstm.cc:228-247,256 and dg[t] is published.
 // ------------------------------------------------------------------------------------------------
-#define BSTAMP_AT(k)                                                                     \
-    if (STAMP && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
-        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+// STAMP builds (LSTM_HIP_DEBUG_STAMPS, N = 512): s_memtime at the points marked BSTAMP, for two workgroups, into a buffer
+// nothing else reads.  Slots [workgroup 0 | gridDim.x/2][t][16]: wave 0 (MFMA + elementwise) 0-7, wave 3 (MFMA, then the
+// dW table) 8-12, wave 5 (MFMA, then output-layer follower) 13-15.
+#define BSTAMP(wave, k)                                                                                        \
+    if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
+        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = __builtin_amdgcn_s_memtime();
+#define BSTAMP_VAL(wave, k, v)                                                                                 \
+    if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
+        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = (unsigned long long)(v);
 // FUSE: the input-side weight-gradient sums (R/lstm.cc:251-252) are accumulated by the same workgroups:
 //   dW[rows, x] += dg_t[rows, col] for the column's input byte x   a [257][64] LDS table kept by one wave that
 //                                                          has no part in the elementwise / publish phase
@@ -1249,15 +953,23 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_g(const float4 *__restri
 // gradient block) in gpart[g]; gemm_fold adds the groups in order afterwards.
 // (Accumulating dU the same way -- 4 x N/16 MFMA accumulator tiles per workgroup -- was built and
 // measured: it needs ~100 more VGPRs, spills, and cost more than the separate GEMM it replaced.)
-template <int NR4W, int COLS, bool FUSE, bool STAMP = false, bool BF16 = false, bool M4 = false>
+// DF (fp32 M4 form only): the data-as-flag hand-off of k_fwd_persistent4 -- dg_t goes into a ring DGx[HX_RING][B][4N] of
+// sentinel-initialised step slots (slot(t) = (t + ring_base) & 3; the backward recurrence walks t downwards, so step t
+// reads slot(t+1), publishes slot(t) and then resets its own words of slot(t-2)); every wave polls the loads of its own
+// K-slice; no counters, no drain, no barrier ahead of the loads (`red` is double-buffered by step parity instead).
+// The plain DG, which the dU product reads after the launch, is stored off the chain.
+template <int NR4W, int COLS, bool FUSE, bool STAMP = false, bool BF16 = false, bool M4 = false, bool DF = false>
 __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restrict__ Ubwd, float *DG,
                                                            const float *__restrict__ DHy, const float *__restrict__ G,
                                                            const float *__restrict__ C, const float *__restrict__ H,
                                                            const int32_t *__restrict__ xi, float *__restrict__ gpart,
                                                            const float *__restrict__ Why, const float *__restrict__ dY,
                                                            unsigned *cnt, unsigned *abortp, unsigned epoch, int S, int B,
-                                                           int stagger, unsigned long long *stamps = nullptr,
-                                                           unsigned short *DGb = nullptr) {
+                                                           int spread, unsigned long long *stamps = nullptr,
+                                                           unsigned short *DGb = nullptr, float *DGx = nullptr,
+                                                           int ring_base = 0) {
+    static_assert(!DF || (M4 && !BF16), "the data-as-flag hand-off exists for the fp32 4x4x1 form");
+    static_assert(!STAMP || M4, "stamped builds exist for the fp32 4x4x1 form");
     constexpr int N = 32 * NR4W, G4 = 4 * N, nr4 = N / 4;
     // BF16: Ubwd holds the bf16 image (N/64 16-byte fragments per wave), dg_{t+1} is read from the bf16 copy DGb
     // (the hand-off), and dg_t is published to DGb (sc1) as well as to DG (fp32, plain, for the dU product)
@@ -1265,7 +977,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     constexpr int ETH = 16 * COLS;        // threads with an elementwise / store role
     constexpr int EW = ETH / 64;          // ... i.e. waves 0..EW-1
     extern __shared__ __attribute__((aligned(16))) float dWt[]; // FUSE: [257][64] per-input-byte sums of this WG's rows
-    __shared__ float red[8 * 4 * 64];
+    __shared__ float red[(DF ? 2 : 1) * 8 * 4 * 64];
     __shared__ __attribute__((aligned(16))) float stage[2][16 * 4 * 16]; // dg of this WG, double-buffered by step parity
     __shared__ int s_abort;
     // FUSE: output-layer followers (waves 4..7): DHy_t = Why^T * dy_t for this workgroup's units, one step
@@ -1277,9 +989,9 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int NBK = gridDim.x, NG = gridDim.y;
     const int lin_ = blockIdx.x + NBK * blockIdx.y;
-    // bit 30 of `stagger` (LSTM_HIP_BWD_SPREAD=1, tests): keep the dispatch-order mapping, which spreads every column
-    // group over all XCDs -- the placement the XCD-local hand-off below must detect and decline
-    const bool remap = GROUP_REMAP && !(stagger & (1 << 30));
+    // `spread` (LSTM_HIP_BWD_SPREAD=1, tests): keep the dispatch-order mapping, which spreads every column group over
+    // all XCDs -- the placement the XCD-local hand-off below must detect and decline
+    const bool remap = GROUP_REMAP && !spread;
     const int kb = remap ? lin_ / NG : (int)blockIdx.x, g = remap ? lin_ % NG : (int)blockIdx.y;
     const int q = l >> 4;
     // COLS = 16: the MFMA tile is full.  COLS = 8: lanes 8..15 of the B operand are never used (their tile
@@ -1298,6 +1010,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                : M4 ? Ubwd[(((size_t)kb * 8 + w) * NR4W + i) * 64 + l] // the 4x4x1 image: see k_pack_U
                     : Ubwd[((size_t)kb * nr4 + w * NR4W + i) * 64 + l];
     const __amdgpu_buffer_rsrc_t rDG = BF16 ? make_rsrc(DGb, (size_t)S * G4 * B * sizeof(unsigned short))
+                                       : DF ? make_rsrc(DGx, (size_t)HX_RING * G4 * B * sizeof(float))
                                             : make_rsrc(DG, (size_t)S * G4 * B * sizeof(float));
     float dcn = 0.0f; // dcnext, R/lstm.cc:217
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1315,9 +1028,11 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     // step-0 counter slots of its group; after the first wait every workgroup of the group reads the same NBK words
     // and takes the plain-store path only if they all agree.  The first publish is always sc1.
     unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE; // step index 0 is never a hand-off step (t = 1..S-1)
-    if (XCD_LOCAL && tid == 0)
+    if (XCD_LOCAL && tid == 0) {
         __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT); // getreg(id 20 = XCC_ID, offset 0, size 4)
+        if (DF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // ahead of the barrier below: visible before any dg
+    }
     unsigned ol_target = 0;
     bool local_pub = false;
     // Why^T A-fragments of the follower waves: wave ow = w-4 takes output rows m in [64*ow, 64*ow+64);
@@ -1338,8 +1053,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
         }
     }
     __syncthreads();
-    if (!STAMP)
-        for (int i = 0; i < g * (stagger & 255); i++) __builtin_amdgcn_s_sleep(32); // see k_fwd_persistent
 
     // dW[:, x] += dg[:, col] (R/lstm.cc:251) for the step whose dg sits in stage[par]: wave EW, one thread per
     // row, walking the columns in order (deterministic); tu is that step
@@ -1363,11 +1076,19 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     // Output-layer work of step tu by the follower waves (R/lstm.cc:226,228):
     //   dhyb[tu&1][c][unit] = sum_m Why[m][unit] * dy_tu[m][c]            (K = 256 split over the 4 waves)
     //   dWhy[m][unit]      += sum_c dy_tu[m][c] * h_tu[unit][c]           (K = COLS)
-    auto ol_sync = [&]() {
-        ol_target += 4;
+    auto ol_sync = [&]() { // the four follower waves meet (LDS counter); bounded like every other spin of the kernel:
+        ol_target += 4;    // a follower that never arrives sets the abort word and the launch ends at its next barrier
         if (l == 0) __hip_atomic_fetch_add(&s_ol, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(&s_ol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ol_target)
-            ;
+        int spins = 0;
+        while (__hip_atomic_load(&s_ol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ol_target) {
+            if (++spins > SPIN_LIMIT) {
+                if (l == 0) {
+                    __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_abort = 1;
+                }
+                break;
+            }
+        }
         asm volatile("" ::: "memory");
     };
     // operands are fetched a whole chain phase ahead of their use (the followers must not arrive late at
@@ -1434,7 +1155,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     }
 
     for (int t = S - 1; t >= 1; t--) {
-        BSTAMP_AT(0)
+        BSTAMP(0, 0) BSTAMP(3, 8) BSTAMP(5, 13)
         const int cur = t & 1;
         const bool has_next = t < S - 1;
         // operands that do not depend on the chain: fetch them first
@@ -1450,9 +1171,9 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
             if (!FUSE) dhy = DHy[((size_t)t * B + ecolc) * N + j];
         }
         if (FUSE && w >= 4 && t >= 2) output_layer_fetch(t - 1);
-        if (has_next && w == 0) {
+        if (!DF && has_next && w == 0) {
             const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
-            if (!wait_arrivals<BWD_SH>(cpn, NBK, epoch * EW, abortp, l, (stagger >> 8) & 0xffff) && l == 0) s_abort = 1;
+            if (!wait_arrivals<BWD_SH>(cpn, NBK, epoch * EW, abortp, l) && l == 0) s_abort = 1;
             if (XCD_LOCAL && t == S - 2) { // every workgroup of the group has published its XCC id by now
                 bool same = true;
                 unsigned mine = 0;
@@ -1467,10 +1188,13 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                 if ((XCD_FORCE_LOCAL || __all(same)) && l == 0) s_local = 1;
             }
         }
-        __syncthreads();
-        if (s_abort) return;
-        if (XCD_LOCAL && t == S - 2) local_pub = s_local != 0; // decided by wave 0 just above; kept in a register
-        BSTAMP_AT(1)
+        if (!DF) {
+            __syncthreads();
+            if (s_abort) return;
+            if (XCD_LOCAL && t == S - 2) local_pub = s_local != 0; // decided by wave 0 just above; kept in a register
+        }
+        BSTAMP(0, 1) BSTAMP(3, 9)
+        float *redp = red + (DF ? (t & 1) * (8 * 4 * 64) : 0);
 
         float dhn = 0.0f;
         if (M4 && has_next) {
@@ -1488,15 +1212,73 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
             const int off = (int)((((size_t)(t + 1) * B + col4c) * G4 + Kw * w + 4 * (2 * lz + ly)) * sizeof(float));
             constexpr int PF = BWD_PF < NL ? BWD_PF : NL;
             float4 b[NL];
-#pragma unroll
-            for (int i = 0; i < PF; i++) b[i] = ld_sc1(rDG, off + 128 * i);
-            __builtin_amdgcn_sched_barrier(0);
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
 #define M4_STEP(av, wq, blgp)                                                          \
     c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.x, c0, 2, 0, blgp);                 \
     c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.y, c1, 2, 1, blgp);                 \
     c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.z, c2, 2, 2, blgp);                 \
     c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.w, c3, 2, 3, blgp);
+            if (DF) {
+                // Data-as-flag with a HINT.  A wave's K-slice is 8 loads per lane (64 KB per workgroup and step: re-issuing
+                // all of them as a poll floods the XCD's L2 -- measured 523 us against 409 with counters).  So: (1) poll ONE
+                // load instruction that touches one 16-byte piece of each of the N/16 producer waves this K-slice comes
+                // from (the piece each stores from its last lane); (2) once those are in, run the usual pipelined loads +
+                // MFMAs, checking every loaded word against the sentinel on the side; (3) in the rare case that some word
+                // had not landed yet (a store instruction's lanes do not land together), drop the sums and repeat (2).
+                // Correctness rests on (2)'s check of every consumed word alone; (1) only decides when to start.
+                const size_t slot_base = (size_t)((t + 1 + ring_base) & (HX_RING - 1)) * B * G4;
+                const int offx = (int)((slot_base + (size_t)col4c * G4 + Kw * w + 4 * (2 * lz + ly)) * sizeof(float));
+                const int gate_k = (Kw * w) / N, unit0 = (Kw * w) % N; // this wave's gate rows: gate_k, units unit0 .. unit0 + Kw
+                const bool hint_lane = l < Kw / 8;                      // Kw/16 producer workgroups x 2 storing waves
+                int hcol = COLS * g + 4 * (l & 1) + 3;
+                hcol = hcol < B ? hcol : B - 1;
+                const int hoff = (int)((slot_base + (size_t)hcol * G4 + gate_k * N + unit0 + 16 * (l >> 1) + 12) * sizeof(float));
+                bool ok = false;
+                int spins = 0;
+                for (; spins <= SPIN_LIMIT; spins++) {
+                    float4 hv = {0.f, 0.f, 0.f, 0.f};
+                    if (hint_lane) hv = ld_sc1(rDG, hoff);
+                    if (__all(hx_ready(hv))) break;
+                    if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        spins = SPIN_LIMIT + 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                BSTAMP(0, 2) BSTAMP(3, 10) BSTAMP_VAL(0, 6, spins)
+                const int spins_hint = spins;
+                for (; spins <= SPIN_LIMIT; spins++) {
+                    bool good = true;
+                    c0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    c1 = c0, c2 = c0, c3 = c0;
+#pragma unroll
+                    for (int i = 0; i < PF; i++) b[i] = ld_sc1(rDG, offx + 128 * i);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < NL; i++) {
+                        if (i + PF < NL) b[i + PF] = ld_sc1(rDG, offx + 128 * (i + PF));
+                        good = good && hx_ready(b[i]);
+                        M4_STEP(b[i].x, a[2 * i], 1)
+                        M4_STEP(b[i].y, a[2 * i], 2)
+                        M4_STEP(b[i].z, a[2 * i + 1], 1)
+                        M4_STEP(b[i].w, a[2 * i + 1], 2)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (__all(good)) {
+                        ok = true;
+                        break;
+                    }
+                    if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                }
+                BSTAMP_VAL(0, 7, spins - spins_hint)
+                if (!ok && l == 0) {
+                    __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_abort = 1;
+                }
+            } else {
+#pragma unroll
+            for (int i = 0; i < PF; i++) b[i] = ld_sc1(rDG, off + 128 * i);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NL; i++) {
                 if (i + PF < NL) b[i + PF] = ld_sc1(rDG, off + 128 * (i + PF));
@@ -1506,15 +1288,18 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                 M4_STEP(b[i].w, a[2 * i + 1], 2)
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
 #undef M4_STEP
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const float v = (c0[r] + c1[r]) + (c2[r] + c3[r]);
                 // the two k-parities y sit 16 lanes apart: fold them (ds_swizzle-free: one bpermute per register)
-                red[(w * 4 + r) * 64 + l] = v + __shfl_xor(v, 16, 64);
+                redp[(w * 4 + r) * 64 + l] = v + __shfl_xor(v, 16, 64);
             }
+            BSTAMP(0, 3) BSTAMP(3, 11) BSTAMP(5, 14)
             __syncthreads();
-            BSTAMP_AT(2)
+            if (DF && s_abort) return;
+            BSTAMP(0, 4) BSTAMP(3, 12) BSTAMP(5, 15)
         } else if (has_next) {
             // Software pipeline with PF fragment loads in flight ahead of the MFMAs.  Left to itself the
             // scheduler keeps only two in flight (a fabric round trip per pair of loads: measured +220
@@ -1526,14 +1311,13 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
             float4 b[NRS];
 #pragma unroll
             for (int i = 0; i < PF; i++)
-                b[i] = (ld_lane && !(STAMP && i >= stagger)) ? ld_sc1(rDG, off + 64 * i) : float4{0.f, 0.f, 0.f, 0.f};
+                b[i] = ld_lane ? ld_sc1(rDG, off + 64 * i) : float4{0.f, 0.f, 0.f, 0.f};
             __builtin_amdgcn_sched_barrier(0);
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NRS; i++) {
                 if (i + PF < NRS)
-                    b[i + PF] = (ld_lane && !(STAMP && i + PF >= stagger)) ? ld_sc1(rDG, off + 64 * (i + PF))
-                                                                           : float4{0.f, 0.f, 0.f, 0.f};
+                    b[i + PF] = ld_lane ? ld_sc1(rDG, off + 64 * (i + PF)) : float4{0.f, 0.f, 0.f, 0.f};
                 if (BF16) {
                     if (i & 1)
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]),
@@ -1557,16 +1341,28 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
 #pragma unroll
             for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
             __syncthreads();
-            BSTAMP_AT(2)
+        } else if (DF) {
+            __syncthreads(); // t = S-1: the one workgroup barrier of a step (LDS hand-offs to the followers and the dW wave)
         }
         if (w < EW) {
+            if (DF && XCD_LOCAL && t == S - 2) { // every workgroup of the group has published dg_{S-1}, its XCC id before it
+                unsigned mine = 0;
+                bool same = true;
+                if (l < NBK) {
+                    mine = __hip_atomic_load(xcc_tab + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    same = (mine >> 4) == epoch;
+                }
+                const unsigned first = __builtin_amdgcn_readfirstlane(mine);
+                if (l < NBK) same = same && mine == first;
+                local_pub = (XCD_FORCE_LOCAL || __all(same)) && NBK <= 64;
+            }
             if (FUSE) dhy = dhyb[cur][cc * 16 + jj]; // written by the followers one step ago (before barrier A)
             if (has_next) {
                 // D[row = 4*(lane>>4) + reg][col = lane&15]  ->  unit jj lives in lane (jj>>2)*16 + cc, reg jj&3
                 // M4: D[reg = column & 3][lane = 32*(column >> 2) + unit]
                 const int src = M4 ? 32 * (cc >> 2) + jj : (jj >> 2) * 16 + cc, reg = M4 ? (cc & 3) : (jj & 3);
 #pragma unroll
-                for (int ww = 0; ww < 8; ww++) dhn += red[(ww * 4 + reg) * 64 + src];
+                for (int ww = 0; ww < 8; ww++) dhn += redp[(ww * 4 + reg) * 64 + src];
             }
             const float dh = dhy + dhn;                         // R/lstm.cc:228
             float dcv = dh * og + dcn;                          // :233
@@ -1607,7 +1403,8 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                     t3 = r1;
                 }
             }
-            BSTAMP_AT(3)
+            BSTAMP(0, 5)
+            if (DF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's older stores (the last reset) are complete
             const float4 v = {t0, t1, t2, t3};
             float4 v2 = v;
             if (BF16) { // the next quad's four units of the same gate: lane + 4 within the row of 16 (row_shl:4)
@@ -1624,6 +1421,22 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                         if (XCD_LOCAL && local_pub) *reinterpret_cast<u32x4 *>(DGb + eoff) = pack_bf16x8(v, v2);
                         else __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v, v2), rDG, (int)(eoff * sizeof(unsigned short)), 0, 16);
                     }
+                } else if (DF) {
+                    const float4 vp = {hx_canon(v.x), hx_canon(v.y), hx_canon(v.z), hx_canon(v.w)};
+                    const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
+                                         __uint_as_float(HX_SENT)};
+                    const size_t within = (size_t)ecol * G4 + ta * N + 16 * kb + 4 * tq;
+                    const size_t e_pub = (size_t)((t + ring_base) & (HX_RING - 1)) * B * G4 + within;
+                    const size_t e_rst = (size_t)((t - 2 + ring_base) & (HX_RING - 1)) * B * G4 + within;
+                    // (the s_waitcnt vmcnt(0) ahead of this block covers the reset issued a step ago)
+                    if (XCD_LOCAL && local_pub) {
+                        *reinterpret_cast<float4 *>(DGx + e_pub) = vp;
+                        *reinterpret_cast<float4 *>(DGx + e_rst) = sent;
+                    } else {
+                        st_sc1(vp, rDG, (int)(e_pub * sizeof(float)));
+                        st_sc1(sent, rDG, (int)(e_rst * sizeof(float)));
+                    }
+                    *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
                 } else {
                     if (XCD_LOCAL && local_pub)
                         *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
@@ -1631,9 +1444,9 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                         st_sc1(v, rDG, (int)((((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) * sizeof(float)));
                 }
             }
-            if (t > 1) {
+            if (!DF && t > 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains, then signals for itself:
-                BSTAMP_AT(4)                                     // EW arrivals per workgroup and step
+                                                                 // EW arrivals per workgroup and step
                 if (l == 0)
                     __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * CNT_SLOTS + (kb & (BWD_SH - 1))) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
@@ -1689,25 +1502,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_wait_progress: lets work on a second stream follow a running recurrence.  One wave waits until
-// every column group's counters show that step t has been published; kernels queued behind it on the
-// same stream then read data that was written through (sc1) before the counters moved.
-// ------------------------------------------------------------------------------------------------
-template <int SH>
-__global__ __launch_bounds__(64) void k_wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch,
-                                                      unsigned *abortp) {
-    for (int g = 0; g < NG; g++)
-        if (!wait_arrivals<SH>(cnt + (size_t)(t * NG + g) * CNT_SLOTS * CNT_STRIDE, n_prod, epoch, abortp, threadIdx.x)) return;
-}
-// backward = false: the forward counters (one arrival per row tile of 4 units); true: the backward counters, where every
-// elementwise wave of a workgroup arrives for itself (`arrivals` per workgroup)
-void wait_progress(unsigned *cnt, int t, int NG, int n_prod, unsigned epoch, unsigned *abortp, hipStream_t st, bool backward,
-                   int arrivals) {
-    if (backward) hipLaunchKernelGGL(k_wait_progress<BWD_SH>, dim3(1), dim3(64), 0, st, cnt, t, NG, n_prod, epoch * arrivals, abortp);
-    else hipLaunchKernelGGL(k_wait_progress<FWD_SH>, dim3(1), dim3(64), 0, st, cnt, t, NG, n_prod, epoch, abortp);
-}
-
-// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 size_t persistent_counter_bytes(int S, int B) {
@@ -1715,81 +1509,121 @@ size_t persistent_counter_bytes(int S, int B) {
     return (size_t)(S + 1) * NG * CNT_SLOTS * CNT_STRIDE * sizeof(unsigned);
 }
 
-template <class K> static int blocks_per_cu(K kernel, int threads) {
+template <class K> static int blocks_per_cu(K kernel, int threads, size_t dyn_lds = 0) {
+    if (dyn_lds > 0)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, dyn_lds) != hipSuccess) return 0;
     return n;
 }
 
 #define FWD_CASES(X) X(1) X(2) X(4) X(8) X(16)
 #define BWD_CASES(X) X(2) X(4) X(8) X(16) X(32)
+constexpr size_t DW_TABLE_BYTES = 257 * 64 * sizeof(float); // dynamic LDS of the fused backward form
 
-// second form of the forward recurrence (k_fwd_persistent2) for N = 128, 256, 512, 1024; LSTM_HIP_FWD_FORM=1 keeps the first
-static bool fwd_second_form(int N) {
-    static const int form = getenv("LSTM_HIP_FWD_FORM") ? atoi(getenv("LSTM_HIP_FWD_FORM")) : 2;
-    return form != 1 && (N == 128 || N == 256 || N == 512 || N == 1024);
+// which forward kernel serves a shape (one rule, no switches):
+//   8-column form (k_fwd_persistent4): N = 256, 512, 1024, more than one 8-column group, one workgroup per CU fits
+//   second form (k_fwd_persistent2):   N = 128, 256, 512, 1024 otherwise (e.g. the evaluator's B = 1)
+//   first form (k_fwd_persistent):     every other multiple of 64
+static bool fwd_second_form(int N) { return N == 128 || N == 256 || N == 512 || N == 1024; }
+bool fwd_uses_8col_form(int N, int B, int n_cus) {
+    return (N == 256 || N == 512 || N == 1024) && B > 8 && (N / 16) * ((B + 7) / 8) <= n_cus;
 }
+// 8-column groups in the backward recurrence when that still fits one workgroup per CU (more CUs pulling fewer bytes
+// each); on v_mfma_f32_4x4x1 for fp32 (N a multiple of 64)
+int bwd_group_cols(int N, int B, int n_cus) { return (N / 16) * ((B + 7) / 8) <= n_cus ? 8 : 16; }
+bool bwd_uses_m4(int N, int cols, bool bf16) { return cols == 8 && !bf16 && N % 64 == 0 && N <= 1024; }
+// floats in one column group's partial gradient block [dW | dU | db | dWhy]
+size_t bwd_partial_floats(int N) { return (size_t)4 * N * 256 + (size_t)4 * N * N + (size_t)4 * N + (size_t)256 * N; }
 
-// third form (k_fwd_persistent3): 8-column groups, one workgroup per CU; N = 256, 512, 1024; LSTM_HIP_FWD_FORM=2 / 1 keep
-// the second / first
-bool fwd_uses_third_form(int N, int B, int n_cus) {
-    static const int form = getenv("LSTM_HIP_FWD_FORM") ? atoi(getenv("LSTM_HIP_FWD_FORM")) : 4;
-    // B <= 8 (a single column group, e.g. the evaluator's B = 1) stays on the second form: no difference measured there
-    // (4, the default, = the same decomposition with the data-as-flag hand-off, k_fwd_persistent4)
-    return form >= 3 && (N == 256 || N == 512 || N == 1024) && B > 8 && (N / 16) * ((B + 7) / 8) <= n_cus;
+// All workgroups of a recurrence wait on each other, so its grid must be co-resident.  The occupancy API is asked about
+// exactly the instantiation that will be launched, with its dynamic LDS; it can over-report by one block per CU
+// (MI355X_MICROARCH.md, residency), so one is taken off wherever more than one is claimed.
+static bool grid_fits(size_t grid, int per_cu, int n_cus) {
+    if (per_cu > 1) per_cu -= 1;
+    if (per_cu > 8) per_cu = 8;
+    return per_cu >= 1 && grid <= (size_t)per_cu * n_cus;
 }
-
-bool persistent_supported(int N, int B, int n_cus) {
+bool persistent_supported(int N, int B, int n_cus, bool fused) {
     if (N % 64 != 0 || N > 1024) return false;
-    int NG = (B + 15) / 16;
-    int fb = 0, bb = 0, fwd_tiles = N / 4;
-    if (fwd_uses_third_form(N, B, n_cus)) {
-        fwd_tiles = N / 16;
-        NG = (B + 7) / 8;
+    int fb = 0, bb = 0;
+    size_t fwd_grid = 0;
+    if (fwd_uses_8col_form(N, B, n_cus)) {
+        fwd_grid = (size_t)(N / 16) * ((B + 7) / 8);
         switch (N / 256) {
-#define X(k) case k: fb = blocks_per_cu(k_fwd_persistent3<k, false>, 512); break;
+#define X(k) case k: fb = blocks_per_cu(k_fwd_persistent4<k, false>, 512); break;
             X(1) X(2) X(4)
 #undef X
         }
-        int fb4 = 0;
-        switch (N / 256) {
-#define X(k) case k: fb4 = blocks_per_cu(k_fwd_persistent4<k, false>, 512); break;
-            X(1) X(2) X(4)
-#undef X
-        }
-        if (fb < 1 || fb4 < 1) return false;
-        fb = 1; // the form is chosen only when one workgroup per CU suffices
     } else if (fwd_second_form(N)) {
-        fwd_tiles = N / 8;
+        fwd_grid = (size_t)(N / 8) * ((B + 15) / 16);
         switch (N / 128) {
 #define X(k) case k: fb = blocks_per_cu(k_fwd_persistent2<k, false>, 512); break;
             X(1) X(2) X(4) X(8)
 #undef X
         }
-    } else
-    switch (N / 64) {
+    } else {
+        fwd_grid = (size_t)(N / 4) * ((B + 15) / 16);
+        switch (N / 64) {
 #define X(k) case k: fb = blocks_per_cu(k_fwd_persistent<k, false>, 256); break;
-        FWD_CASES(X)
+            FWD_CASES(X)
 #undef X
-        default: return false;
+            default: return false;
+        }
     }
+    const int cols = bwd_group_cols(N, B, n_cus);
+    const bool fuse = fused && cols == 8;
+    const size_t lds = fuse ? DW_TABLE_BYTES : 0;
     switch (N / 32) {
-#define X(k) case k: bb = blocks_per_cu(k_bwd_persistent<k, 16, false, false>, 512); break;
+#define X(k)                                                                                                           \
+    case k:                                                                                                            \
+        if (cols == 8 && fuse) bb = blocks_per_cu(k_bwd_persistent<k, 8, true, false, false, true, true>, 512, lds);   \
+        else if (cols == 8) bb = blocks_per_cu(k_bwd_persistent<k, 8, false, false, false, true, true>, 512, 0);       \
+        else bb = blocks_per_cu(k_bwd_persistent<k, 16, false>, 512, 0);                                               \
+        break;
         BWD_CASES(X)
 #undef X
         default: return false;
     }
-    // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md, residency): keep a margin
-    if (fb > 1) fb -= 1;
-    if (bb > 1) bb -= 1;
-    if (fb > 8) fb = 8;
-    return (size_t)fwd_tiles * NG <= (size_t)fb * n_cus && (size_t)(N / 16) * ((B + 15) / 16) <= (size_t)bb * n_cus;
+    return grid_fits(fwd_grid, fb, n_cus) && grid_fits((size_t)(N / 16) * ((B + cols - 1) / cols), bb, n_cus);
+}
+// the bf16 recurrence launches other instantiations on other grids (8-column groups in the backward recurrence always)
+bool persistent_supported_bf16(int N, int B, int n_cus, bool fused) {
+    if (N % 128 != 0 || N > 1024) return false;
+    int fb = 0, bb = 0;
+    size_t fwd_grid = 0;
+    if (N % 256 == 0) {
+        fwd_grid = (size_t)(N / 8) * ((B + 15) / 16);
+        switch (N / 256) {
+#define X(k) case k: fb = blocks_per_cu(k_fwd_persistent2_bf16<k, false>, 512); break;
+            X(1) X(2) X(4)
+#undef X
+        }
+    } else {
+        fwd_grid = (size_t)(N / 4) * ((B + 15) / 16);
+        switch (N / 128) {
+#define X(k) case k: fb = blocks_per_cu(k_fwd_persistent_bf16<k, false>, 256); break;
+            X(1) X(2) X(4) X(8)
+#undef X
+        }
+    }
+    switch (N / 32) {
+#define X(k)                                                                                             \
+    case k:                                                                                              \
+        bb = fused ? blocks_per_cu(k_bwd_persistent<k, 8, true, false, true>, 512, DW_TABLE_BYTES)       \
+                   : blocks_per_cu(k_bwd_persistent<k, 8, false, false, true>, 512, 0);                  \
+        break;
+        X(4) X(8) X(16) X(32)
+#undef X
+    }
+    return grid_fits(fwd_grid, fb, n_cus) && grid_fits((size_t)(N / 16) * ((B + 7) / 8), bb, n_cus);
 }
 
+// ---- forward ---------------------------------------------------------------------------------------------------------
 void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
                     const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B, bool fast,
-                    hipStream_t st, unsigned long long *stamps) {
-    if (stamps == nullptr && fwd_second_form(N)) {
+                    hipStream_t st) {
+    if (fwd_second_form(N)) {
         const dim3 grid2(N / 8, (B + 15) / 16), block2(512);
         switch (N / 128) {
 #define X(k)                                                                                                          \
@@ -1803,32 +1637,13 @@ void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float
         return;
     }
     const dim3 grid(N / 4, (B + 15) / 16), block(256);
-    static const int stagger = getenv("LSTM_HIP_FWD_STAGGER") ? atoi(getenv("LSTM_HIP_FWD_STAGGER")) : 0;
-    if (stamps != nullptr && N == 512) { // diagnostic build of the headline shape
-        hipLaunchKernelGGL((k_fwd_persistent<8, false, true>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B, stagger, stamps);
-        return;
-    }
     switch (N / 64) {
 #define X(k)                                                                                                          \
     case k:                                                                                                           \
-        if (fast) hipLaunchKernelGGL((k_fwd_persistent<k, true>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B, stagger, nullptr); \
-        else hipLaunchKernelGGL((k_fwd_persistent<k, false>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B, stagger, nullptr);    \
+        if (fast) hipLaunchKernelGGL((k_fwd_persistent<k, true>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B); \
+        else hipLaunchKernelGGL((k_fwd_persistent<k, false>), grid, block, 0, st, Ufwd, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B);    \
         break;
         FWD_CASES(X)
-#undef X
-    }
-}
-
-void fwd_persistent3(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
-                     unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B, bool fast, hipStream_t st) {
-    const dim3 grid(N / 16, (B + 7) / 8), block(512);
-    switch (N / 256) {
-#define X(k)                                                                                                          \
-    case k:                                                                                                           \
-        if (fast) hipLaunchKernelGGL((k_fwd_persistent3<k, true>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B); \
-        else hipLaunchKernelGGL((k_fwd_persistent3<k, false>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, cnt, abortp, epoch, S, B);    \
-        break;
-        X(1) X(2) X(4)
 #undef X
     }
 }
@@ -1837,54 +1652,29 @@ size_t fwd_ring_floats(int N, int B) { return (size_t)HX_RING * N * B; }
 int fwd_ring_advance(int ring_base, int S) { return (ring_base + S - 1) & (HX_RING - 1); }
 void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
-                     int poll_cfg, hipStream_t st) {
+                     int poll_cfg, hipStream_t st, unsigned long long *stamps) {
     const dim3 grid(N / 16, (B + 7) / 8), block(512);
+    if (stamps != nullptr && N == 512) { // diagnostic build of the headline shape
+        hipLaunchKernelGGL((k_fwd_persistent4<2, false, true>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, Hx, cnt, abortp,
+                           epoch, ring_base, S, B, poll_cfg, stamps);
+        return;
+    }
     switch (N / 256) {
 #define X(k)                                                                                                          \
     case k:                                                                                                           \
-        if (fast) hipLaunchKernelGGL((k_fwd_persistent4<k, true>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch, ring_base, S, B, poll_cfg); \
-        else hipLaunchKernelGGL((k_fwd_persistent4<k, false>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch, ring_base, S, B, poll_cfg);    \
+        if (fast) hipLaunchKernelGGL((k_fwd_persistent4<k, true>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch, ring_base, S, B, poll_cfg, nullptr); \
+        else hipLaunchKernelGGL((k_fwd_persistent4<k, false>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch, ring_base, S, B, poll_cfg, nullptr);    \
         break;
         X(1) X(2) X(4)
 #undef X
     }
 }
 
-void fwd_persistent_granules(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
-                              unsigned long long *Hg, const int32_t *xi, unsigned *abortp, unsigned epoch_base, int N,
-                              int S, int B, bool fast, hipStream_t st) {
-    const dim3 grid(N / 4, (B + 15) / 16), block(256);
-    switch (N / 64) {
-#define X(k)                                                                                                           \
-    case k:                                                                                                            \
-        if (fast) hipLaunchKernelGGL((k_fwd_persistent_g<k, true>), grid, block, 0, st, Ufwd, W, bias, H, C, G, Hg, xi, abortp, epoch_base, S, B); \
-        else hipLaunchKernelGGL((k_fwd_persistent_g<k, false>), grid, block, 0, st, Ufwd, W, bias, H, C, G, Hg, xi, abortp, epoch_base, S, B);    \
-        break;
-        FWD_CASES(X)
-#undef X
-    }
-}
-
-// the 4x4x1 form of the backward recurrence: fp32, 8-column groups, N a multiple of 64; LSTM_HIP_BWD_M4=0 keeps the
-// half-empty 16x16x4 tiles (A/B switch)
-bool bwd_uses_m4(int N, int cols, bool bf16) {
-    static const int on = getenv("LSTM_HIP_BWD_M4") ? atoi(getenv("LSTM_HIP_BWD_M4")) : 1;
-    return on != 0 && cols == 8 && !bf16 && N % 64 == 0 && N <= 1024;
-}
-// 8-column groups when that still fits one workgroup per CU (more CUs pulling fewer bytes each)
-int bwd_group_cols(int N, int B, int n_cus) {
-    static const int force = getenv("LSTM_HIP_BWD_COLS") ? atoi(getenv("LSTM_HIP_BWD_COLS")) : 0;
-    if (force == 8 || force == 16) return force;
-    return (N / 16) * ((B + 7) / 8) <= n_cus ? 8 : 16;
-}
-// floats in one column group's partial gradient block [dW | dU | db]
-size_t bwd_partial_floats(int N) { return (size_t)4 * N * 256 + (size_t)4 * N * N + (size_t)4 * N + (size_t)256 * N; }
-
 void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, float *H, unsigned short *Hb, float *C,
                          float *G, const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
                          bool fast, hipStream_t st) {
     const u32x4 *U16 = reinterpret_cast<const u32x4 *>(Ufwd16);
-    if (fwd_second_form(N) && N % 256 == 0) {
+    if (N % 256 == 0) {
         const dim3 grid2(N / 8, (B + 15) / 16), block2(512);
         switch (N / 256) {
 #define X(k)                                                                                                             \
@@ -1909,91 +1699,73 @@ void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, 
     }
 }
 
+// ---- backward --------------------------------------------------------------------------------------------------------
+size_t bwd_ring_floats(int N, int B) { return (size_t)HX_RING * 4 * N * B; }
+int bwd_ring_advance(int ring_base, int S) { return (ring_base - (S - 1)) & (HX_RING - 1); }
+
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,
                     const int32_t *xi, float *gpart, const float *Why, const float *dY, unsigned *cnt, unsigned *abortp,
                     unsigned epoch, int N, int S, int B, int cols, hipStream_t st, unsigned long long *stamps,
-                    unsigned short *DGb) {
+                    unsigned short *DGb, float *DGx, int ring_base) {
     const dim3 grid(N / 16, (B + cols - 1) / cols), block(512);
-    if (DGb != nullptr) { // bf16 recurrence: 8-column groups; fused when gpart is given
-        const bool fuse16 = gpart != nullptr;
-        const size_t lds16 = fuse16 ? 257 * 64 * sizeof(float) : 0;
+    const bool fuse = gpart != nullptr;
+    const size_t lds = fuse ? DW_TABLE_BYTES : 0;
+    // test hook: LSTM_HIP_BWD_SPREAD=1 keeps the dispatch-order workgroup mapping (column groups spread over all XCDs)
+    static const int spread = getenv("LSTM_HIP_BWD_SPREAD") && atoi(getenv("LSTM_HIP_BWD_SPREAD")) ? 1 : 0;
+#define BWD_GO(...)                                                                                                    \
+    do {                                                                                                               \
+        if (fuse) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persistent<__VA_ARGS__>),           \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_TABLE_BYTES);          \
+        hipLaunchKernelGGL((k_bwd_persistent<__VA_ARGS__>), grid, block, lds, st, Ubwd, DG, DHy, G, C, H, xi, gpart, Why, dY, cnt, \
+                           abortp, epoch, S, B, spread, stamps, DGb, DGx, ring_base);                                   \
+    } while (0)
+    if (DGb != nullptr) { // bf16 recurrence: 8-column groups, 16x16x32 tiles, counter hand-off
         switch (N / 32) {
-#define X(k)                                                                                                              \
-    case k:                                                                                                               \
-        if (fuse16) {                                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persistent<k, 8, true, false, true>),       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 257 * 64 * sizeof(float));             \
-            hipLaunchKernelGGL((k_bwd_persistent<k, 8, true, false, true>), grid, block, lds16, st, Ubwd, DG, DHy, G, C, H, xi, \
-                               gpart, Why, dY, cnt, abortp, epoch, S, B, 0, nullptr, DGb);                                \
-        } else {                                                                                                          \
-            hipLaunchKernelGGL((k_bwd_persistent<k, 8, false, false, true>), grid, block, 0, st, Ubwd, DG, DHy, G, C, H, xi, \
-                               gpart, Why, dY, cnt, abortp, epoch, S, B, 0, nullptr, DGb);                                \
-        }                                                                                                                 \
+#define X(k)                                            \
+    case k:                                             \
+        if (fuse) BWD_GO(k, 8, true, false, true);      \
+        else BWD_GO(k, 8, false, false, true);          \
         break;
             X(4) X(8) X(16) X(32)
 #undef X
         }
         return;
     }
-    static const int stagger = (getenv("LSTM_HIP_BWD_STAGGER") ? atoi(getenv("LSTM_HIP_BWD_STAGGER")) & 0xffffff : 0) |
-                               (getenv("LSTM_HIP_BWD_SPREAD") && atoi(getenv("LSTM_HIP_BWD_SPREAD")) ? (1 << 30) : 0);
-    const bool fuse = gpart != nullptr;
-    const size_t lds = fuse ? 257 * 64 * sizeof(float) : 0;
     if (bwd_uses_m4(N, cols, false)) { // Ubwd is the 4x4x1 image here (the caller packs it when bwd_uses_m4 says so)
-#define BWD_LAUNCH4(k, f, s)                                                                                          \
-    do {                                                                                                              \
-        if (f) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persistent<k, 8, f, s, false, true>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 257 * 64 * sizeof(float));      \
-        hipLaunchKernelGGL((k_bwd_persistent<k, 8, f, s, false, true>), grid, block, lds, st, Ubwd, DG, DHy, G, C, H, xi, gpart, \
-                           Why, dY, cnt, abortp, epoch, S, B, stagger, stamps);                                             \
-    } while (0)
-        if (stamps != nullptr && N == 512) {
-            if (fuse) BWD_LAUNCH4(16, true, true);
-            else BWD_LAUNCH4(16, false, true);
+        if (stamps != nullptr && N == 512) { // diagnostic build of the headline shape
+            if (DGx != nullptr) {
+                if (fuse) BWD_GO(16, 8, true, true, false, true, true);
+                else BWD_GO(16, 8, false, true, false, true, true);
+            } else {
+                if (fuse) BWD_GO(16, 8, true, true, false, true, false);
+                else BWD_GO(16, 8, false, true, false, true, false);
+            }
             return;
         }
         stamps = nullptr;
         switch (N / 32) {
-#define X(k)                                  \
-    case k:                                   \
-        if (fuse) BWD_LAUNCH4(k, true, false); \
-        else BWD_LAUNCH4(k, false, false);     \
+#define X(k)                                                                   \
+    case k:                                                                    \
+        if (DGx != nullptr) {                                                  \
+            if (fuse) BWD_GO(k, 8, true, false, false, true, true);            \
+            else BWD_GO(k, 8, false, false, false, true, true);                \
+        } else {                                                               \
+            if (fuse) BWD_GO(k, 8, true, false, false, true, false);           \
+            else BWD_GO(k, 8, false, false, false, true, false);               \
+        }                                                                      \
         break;
             X(2) X(4) X(8) X(16) X(32)
 #undef X
         }
-#undef BWD_LAUNCH4
-        return;
-    }
-#define BWD_LAUNCH(k, c, f, s)                                                                                        \
-    do {                                                                                                              \
-        if (f) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persistent<k, c, f, s>),              \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 257 * 64 * sizeof(float));      \
-        hipLaunchKernelGGL((k_bwd_persistent<k, c, f, s>), grid, block, lds, st, Ubwd, DG, DHy, G, C, H, xi, gpart, Why, dY, \
-                           cnt, abortp, epoch, S, B, stagger, stamps);                                                     \
-    } while (0)
-    if (stamps != nullptr && N == 512) {
-        if (cols == 8 && fuse) BWD_LAUNCH(16, 8, true, true);
-        else if (cols == 8) BWD_LAUNCH(16, 8, false, true);
-        else BWD_LAUNCH(16, 16, false, true);
         return;
     }
     stamps = nullptr;
-    switch (N / 32) {
-#define X(k)                                    \
-    case k:                                     \
-        if (cols == 8) {                        \
-            if (fuse) BWD_LAUNCH(k, 8, true, false);  \
-            else BWD_LAUNCH(k, 8, false, false);      \
-        } else {                                \
-            if (fuse) BWD_LAUNCH(k, 16, true, false); \
-            else BWD_LAUNCH(k, 16, false, false);     \
-        }                                       \
-        break;
+    switch (N / 32) { // 16-column groups on 16x16x4 tiles (batches too large for 8-column groups on one workgroup per CU)
+#define X(k) case k: BWD_GO(k, 16, false); break;
         BWD_CASES(X)
 #undef X
     }
-#undef BWD_LAUNCH
+#undef BWD_GO
 }
 
 } // namespace lstmk

@@ -23,6 +23,7 @@
 // --lr-warmup-windows X applies lr = 0 for the first X windows (the reference's GPU driver uses
 // X = 50*S, OV/lstm_eigen_class_CUDA/lstm.cc:364-367; 0 = the root file's behaviour).
 #include "../../include/lstm_hip.h"
+#include "matrix_io.h"
 #include "rng.h"
 
 #include <sys/time.h>
@@ -101,7 +102,7 @@ double count_flops(double M, double N, double S, double B) {
 }
 
 // Parameters::save_to_disk / load_from_disk, OV/lstm_eigen_class_CUDA/lstm.h:83-101, io.h:16-74:
-// five text files <prefix>_{W,U,Why,b,by}.txt, one matrix row per line, 6 significant digits.
+// five text files <prefix>_{W,U,Why,b,by}.txt in the reference's own layout (matrix_io.h): loadable by either program.
 struct Block {
     const char *name;
     size_t rows, cols, off;
@@ -122,65 +123,34 @@ std::vector<Block> blocks(int N, int M) {
 }
 void save_params(const std::string &prefix, const std::vector<float> &P, int N, int M, int digits = 6) {
     for (const Block &b : blocks(N, M)) {
-        std::ofstream f(prefix + "_" + b.name + ".txt");
-        if (!f) die("cannot write " + prefix + "_" + b.name + ".txt");
-        f.precision(digits);
-        for (size_t r = 0; r < b.rows; r++) {
-            for (size_t c = 0; c < b.cols; c++) f << (c ? " " : "") << P[b.off + c * b.rows + r];
-            f << "\n";
-        }
+        const std::string path = prefix + "_" + b.name + ".txt";
+        if (!matrix_io::write_matrix(path, b.rows, b.cols, [&](size_t r, size_t c) { return P[b.off + c * b.rows + r]; }, digits))
+            die("cannot write " + path);
     }
 }
 bool load_params(const std::string &prefix, std::vector<float> &P, int N, int M) {
     for (const Block &b : blocks(N, M)) {
-        std::ifstream f(prefix + "_" + b.name + ".txt");
-        if (!f) return false;
-        std::string line;
-        size_t r = 0;
-        while (std::getline(f, line)) {
-            std::istringstream ss(line);
-            double v;
-            size_t c = 0;
-            while (ss >> v) {
+        const std::string path = prefix + "_" + b.name + ".txt";
+        size_t rows = 0, cols = 0;
+        if (!std::ifstream(path).good()) return false;
+        if (!matrix_io::read_matrix(path, [&](size_t r, size_t c, double v) {
                 if (r < b.rows && c < b.cols) P[b.off + c * b.rows + r] = (float)v;
-                c++;
-            }
-            if (c == 0) continue;
-            if (c != b.cols) die(prefix + "_" + b.name + ".txt: row " + std::to_string(r) + " has " + std::to_string(c) + " columns");
-            r++;
-        }
-        if (r != b.rows) die(prefix + "_" + b.name + ".txt: " + std::to_string(r) + " rows, expected " + std::to_string(b.rows));
+            }, &rows, &cols))
+            die(path + ": rows of different lengths");
+        if (rows != b.rows || cols != b.cols)
+            die(path + ": " + std::to_string(rows) + " x " + std::to_string(cols) + ", expected " + std::to_string(b.rows) + " x " +
+                std::to_string(b.cols));
     }
     return true;
 }
 
-
 // results log, OV/lstm_eigen_class_CUDA/lstm.cc:203-226 + io.h:16-30: the whole 5-column matrix is rewritten after
-// every test, printed the way Eigen's operator<< does (6 significant digits, one common column width)
+// every test, in the same layout
 void write_results(const std::string &path, const std::vector<std::vector<double>> &rows) {
-    std::vector<std::vector<std::string>> cells;
-    size_t width = 0;
-    for (const auto &r : rows) {
-        cells.emplace_back();
-        for (double v : r) {
-            std::ostringstream ss;
-            ss.precision(6);
-            ss << (float)v;
-            width = std::max(width, ss.str().size());
-            cells.back().push_back(ss.str());
-        }
-    }
     printf("Saving a matrix to %s... \n", path.c_str());
-    std::ofstream f(path);
-    if (!f) {
+    if (!matrix_io::write_matrix(path, rows.size(), rows.empty() ? 0 : rows[0].size(),
+                                 [&](size_t r, size_t c) { return (float)rows[r][c]; }))
         printf("file save error: (%s)\n", path.c_str());
-        return;
-    }
-    for (size_t r = 0; r < cells.size(); r++) {
-        for (size_t c = 0; c < cells[r].size(); c++)
-            f << (c ? " " : "") << std::string(width - cells[r][c].size(), ' ') << cells[r][c];
-        if (r + 1 < cells.size()) f << "\n";
-    }
 }
 void save_cursors(const std::string &prefix, const std::vector<uint64_t> &pos) {
     std::ofstream f(prefix + "_cursors.txt");

@@ -18,11 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LSTM_HIP_LIB", os.path.join(HERE, "liblstm_hip.so"))  # env override: A/B builds only
 
 FAST_MATH = 1
-NO_GRAPH = 2
 STEP_KERNELS = 4
-GRANULE_HANDOFF = 8
 DEBUG_STAMPS = 16
-NO_OVERLAP = 32
 NO_FUSED_GRADS = 64
 BF16_RECURRENCE = 128
 LOSS_ALL_STEPS_BITS, LOSS_LAST_STEP_NATS = 0, 1
@@ -47,7 +44,7 @@ _lib = None
 SYMBOLS = [
     "lstm_hip_create", "lstm_hip_destroy", "lstm_hip_last_error", "lstm_hip_param_count", "lstm_hip_set_params",
     "lstm_hip_get_params", "lstm_hip_set_state", "lstm_hip_get_state", "lstm_hip_get_activations",
-    "lstm_hip_set_window", "lstm_hip_slide_state", "lstm_hip_forward", "lstm_hip_loss", "lstm_hip_backward",
+    "lstm_hip_set_window", "lstm_hip_set_inputs_dense", "lstm_hip_slide_state", "lstm_hip_forward", "lstm_hip_loss", "lstm_hip_backward",
     "lstm_hip_adagrad", "lstm_hip_comm_unique_id", "lstm_hip_comm_init", "lstm_hip_allreduce_grads",
     "lstm_hip_set_text", "lstm_hip_set_cursors", "lstm_hip_get_cursors", "lstm_hip_reset_window",
     "lstm_hip_get_window", "lstm_hip_train_windows", "lstm_hip_set_global_batch", "lstm_hip_set_loss_mode", "lstm_hip_set_stride", "lstm_hip_eval_bits",
@@ -167,6 +164,16 @@ class Lstm:
         assert xi.shape == (self.S, self.B) and ti.shape == (self.S, self.B)
         _chk(self.lib.lstm_hip_set_window(self._h, _ptr(xi, C.c_int32), _ptr(ti, C.c_int32)))
 
+    def set_inputs_dense(self, x, target, h0=None, c0=None):
+        """copy_inputs_to_device with the reference's own operands: dense one-hot x[t], target[t] as [S, B, M] arrays
+        (= M x B column-major matrices back to back) and optionally h[0], c[0] as [B, N]."""
+        x, target = _f32(x), _f32(target)
+        assert x.shape == (self.S, self.B, self.M) and target.shape == (self.S, self.B, self.M)
+        h0 = None if h0 is None else _f32(h0)
+        c0 = None if c0 is None else _f32(c0)
+        _chk(self.lib.lstm_hip_set_inputs_dense(self._h, _ptr(h0) if h0 is not None else None,
+                                                _ptr(c0) if c0 is not None else None, _ptr(x), _ptr(target)))
+
     def get_window(self):
         xi = np.empty((self.S, self.B), np.int32)
         ti = np.empty((self.S, self.B), np.int32)
@@ -253,7 +260,7 @@ class Lstm:
         return out, h0, c0
 
     def debug_stamps(self):
-        out = np.zeros((4, self.S, 8), np.uint64)  # [fwd wg0, fwd wg1, bwd wg0, bwd wg1]
+        out = np.zeros((4, self.S, 16), np.uint64)  # [fwd wg0, fwd wg1, bwd wg0, bwd wg1][step][slot]
         _chk(self.lib.lstm_hip_debug_stamps(self._h, _ptr(out, C.c_uint64), C.c_size_t(out.size)))
         return out
 

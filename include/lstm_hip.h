@@ -44,20 +44,17 @@ extern "C" {
 /* flags for lstm_hip_config.flags */
 #define LSTM_HIP_FAST_MATH 1u      /* v_exp/v_rcp based sigmoid/tanh (the reference's --use_fast_math build,
                                       OV/lstm_eigen_class_CUDA/Makefile:53-66); default is libm-accurate */
-#define LSTM_HIP_NO_GRAPH 2u       /* launch kernels eagerly instead of replaying a captured hipGraph */
+                                   /* (bits 2u, 8u, 32u: flags of earlier versions, now ignored) */
 #define LSTM_HIP_STEP_KERNELS 4u   /* one launch per timestep (baseline engine) instead of the persistent
                                       recurrence kernels */
-#define LSTM_HIP_GRANULE_HANDOFF 8u /* forward hand-off by 8-byte {value, tag} granules instead of the default sc1
-                                      payload + sharded counters (measured 1.6-1.9x slower; kept for A/B runs) */
 
 #define LSTM_HIP_BF16_RECURRENCE 128u /* bf16 MFMA in the two recurrent products (U and the h / dg hand-off rounded to
                                       bfloat16, fp32 accumulate, fp32 master weights and everything else);
                                       needs N % 128 == 0 */
 #define LSTM_HIP_NO_FUSED_GRADS 64u  /* compute dU/dW/db after the backward recurrence (GEMM + sorted segment sums)
                                       instead of accumulating them inside it */
-#define LSTM_HIP_NO_OVERLAP 32u      /* run the time-batched products after the recurrences instead of beside them */
-#define LSTM_HIP_DEBUG_STAMPS 16u    /* diagnostic build of the forward recurrence (N = 512) that records
-                                      s_memtime at five points of every step; see lstm_hip_debug_stamps */
+#define LSTM_HIP_DEBUG_STAMPS 16u    /* diagnostic builds of both recurrences (N = 512, 8-column forms) that record
+                                      s_memtime at marked points of every step; see lstm_hip_debug_stamps */
 
 typedef struct lstm_hip_ctx lstm_hip_t; /* opaque: cuParameters p,d,m + cuLSTM<S> in one object */
 
@@ -96,6 +93,12 @@ int lstm_hip_get_activations(lstm_hip_t *h, int32_t t, float *g_t, float *probs_
 /* ---- copy_inputs_to_device, cu_lstm.h:364-377: the window's inputs and targets as indices,
  *      xi[t*B+b], ti[t*B+b], t in [0,S) (row 0 is never read, as in the reference). */
 int lstm_hip_set_window(lstm_hip_t *h, const int32_t *xi, const int32_t *ti);
+/* the same call with the reference's own operands: h[0], c[0] (N x B each, may be NULL = leave as is) and the dense one-hot
+ * matrices x[t], target[t] (M x B each, column-major, t = 0..S-1 back to back: S*B columns of M floats).  Every column must
+ * be all-zero or exactly one 1.0f among zeros (what the reference's encoder produces, R/lstm.cc:169-170,
+ * OV/lstm_eigen_opt/lstm.cc:199-212); anything else is LSTM_HIP_EINVAL.  For bit-faithful lock-step tests against code
+ * that holds the dense form. */
+int lstm_hip_set_inputs_dense(lstm_hip_t *h, const float *h0, const float *c0, const float *x, const float *target);
 /* the device-side part of the slide (OV/lstm_eigen_opt/lstm.cc:205-206): h[0] <- h[1], c[0] <- c[1] */
 int lstm_hip_slide_state(lstm_hip_t *h);
 
@@ -150,9 +153,10 @@ int lstm_hip_eval_bits(lstm_hip_t *h, const uint8_t *text, size_t len, double *b
 int lstm_hip_sample(lstm_hip_t *h, float *h0, float *c0, const double *u, int32_t count, uint8_t *out);
 
 /* ---- measurement.  With profiling on, every kernel launch is bracketed by HIP events on the
- *      handle's stream (the graph path is bypassed) and per-kernel totals accumulate. */
+ *      handle's stream and per-kernel totals accumulate. */
 int lstm_hip_synchronize(lstm_hip_t *h);
-/* [2 workgroups][S][8] shader-clock stamps of the last forward (LSTM_HIP_DEBUG_STAMPS handles only) */
+/* [forward, backward][2 workgroups][S][16] shader-clock stamps of the last window (LSTM_HIP_DEBUG_STAMPS handles only;
+ * slot meanings: persistent.hip, FSTAMP / BSTAMP) */
 int lstm_hip_debug_stamps(lstm_hip_t *h, uint64_t *out, size_t count);
 int lstm_hip_set_profiling(lstm_hip_t *h, int32_t on);
 int lstm_hip_kernel_stat_count(lstm_hip_t *h);

@@ -72,3 +72,32 @@ def test_host_rng_and_cursors_match_the_oracle_spec(oracle32):
         tr.slide()
     # after 3 slides the newest target of stream b is text[pos[b] + 2]
     assert [int(v) for v in tr.ti[6]] == [int(text[int(p) + 2]) for p in pos]
+
+
+def _reference_reader_rows(path):
+    """The row count the reference's readMatrix would reach (OV/lstm_eigen_class_CUDA/io.h:36-74): it calls getline
+    until eof is set, counting every line -- including the empty one a trailing newline produces."""
+    data = open(path, "rb").read().decode()
+    return len(data.split("\n"))
+
+
+@pytest.mark.parametrize("name,rows,cols", [("ref_saved_test4_b.txt", 64, 1), ("ref_saved_test4_Why.txt", 256, 16)])
+def test_checkpoint_text_layout_is_the_references(tmp_path, name, rows, cols):
+    """Parameters::save_to_disk files written by the host program must be loadable by the reference (and vice versa):
+    same layout as Eigen's operator<< (matrix_io.h).  A file the REFERENCE saved (tests/golden/ref_saved_*, data) is read
+    by the host program's reader and written back by its writer: byte-identical, and the reference's eof/getline reader
+    loop sees exactly `rows` rows (no trailing newline)."""
+    import subprocess
+    exe = tmp_path / "host_io_roundtrip"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "host_io_roundtrip.cc"), "-o", str(exe)])
+    src = os.path.join(ROOT, "tests", "golden", name)
+    out = tmp_path / "out.txt"
+    dims = subprocess.check_output([str(exe), src, str(out)], text=True).split()
+    assert [int(d) for d in dims] == [rows, cols]
+    assert open(src, "rb").read() == open(out, "rb").read()
+    assert _reference_reader_rows(out) == rows
+    # 9 digits round-trip float32 exactly (the resumable checkpoint's Adagrad memory)
+    out9, back = tmp_path / "out9.txt", tmp_path / "back.txt"
+    subprocess.check_call([str(exe), src, str(out9), "9"])
+    subprocess.check_call([str(exe), str(out9), str(back)])
+    assert open(src, "rb").read() == open(back, "rb").read()

@@ -101,10 +101,10 @@ def test_window_matches_oracle(N, S, B, empty, oracle32):
     np.testing.assert_allclose(got["mem"], mref, rtol=1e-3, atol=1e-3 * float(mref.max()))
 
 
-@pytest.mark.parametrize("flag_name", ["GRANULE_HANDOFF", "NO_FUSED_GRADS", "STEP_KERNELS"])
+@pytest.mark.parametrize("flag_name", ["NO_FUSED_GRADS", "STEP_KERNELS"])
 def test_alternative_engines_agree(flag_name, oracle32):
-    """The A/B switches kept in the library (granule hand-off, unfused dW/db, per-step engine) compute the
-    same window as the default path."""
+    """The alternative engines kept in the library (unfused dW/db/DHy/dWhy, per-step engine) compute the same window as
+    the default path."""
     import lstm_hip
     N, S, B = 128, 9, 24
     P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=31, empty=((1, 3),))
@@ -158,6 +158,72 @@ def test_fast_math_flag_stays_close(oracle32):
     for t in range(1, S):
         assert gu.max_rel(got["h"][t - 1], fw["h"][t]) <= 1e-4
     assert abs(got["loss"] - fw["loss_bits"]) <= 1e-4 * (S - 1)
+
+
+def test_backward_data_as_flag_handoff_matches_oracle(oracle32, monkeypatch):
+    """LSTM_HIP_BWD_HANDOFF=flag (read per handle at create): the backward recurrence hands dg over through the sentinel
+    ring (hint poll + checked, pipelined loads) instead of the sharded counters.  Same window, same tolerances, across
+    several windows so that the ring wraps and its slots are reused between launches (S-1 not a multiple of 4)."""
+    import lstm_hip
+    from oracle_lib import Oracle
+    N, S, B = 256, 12, 64
+    monkeypatch.setenv("LSTM_HIP_BWD_HANDOFF", "flag")
+    L = lstm_hip.Lstm(N, S, B)
+    monkeypatch.delenv("LSTM_HIP_BWD_HANDOFF")
+    orc = Oracle("f32_omp")
+    for rep in range(5):
+        P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=300 + rep, empty=((1, rep),))
+        fw = orc.forward(N, 256, S, B, P, xi, ti, h0, c0)
+        dref = orc.backward(N, 256, S, B, P, xi, ti, fw)
+        L.set_params(P)
+        L.set_state(0, h0, c0)
+        L.set_window(xi, ti)
+        L.forward()
+        assert abs(L.loss() - fw["loss_bits"]) <= LOSS_TOL * (S - 1)
+        L.backward()
+        rep_ = gu.grads_report(L.get_grads(), dref, N)
+        assert max(rep_.values()) <= GRAD_TOL, (rep, rep_)
+    L.close()
+
+
+def test_dense_one_hot_inputs_entry_point(oracle32):
+    """lstm_hip_set_inputs_dense = copy_inputs_to_device (OV/lstm_eigen_class_CUDA/cu_lstm.h:364-377) with the reference's
+    own operands: the dense one-hot x[t], target[t] and h[0], c[0].  Same window as through the index form, bit for bit;
+    a column that is not one-hot is refused."""
+    import lstm_hip
+    N, S, B = 64, 6, 20
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=8, empty=((1, 0), (2, 19)))
+    eye = np.vstack([np.eye(256, dtype=np.float32), np.zeros((1, 256), np.float32)])  # row -1 -> the all-zero column
+    x, tg = eye[xi], eye[ti]
+
+    def run(dense):
+        L = lstm_hip.Lstm(N, S, B)
+        L.set_params(P)
+        if dense:
+            L.set_inputs_dense(x, tg, h0, c0)
+        else:
+            L.set_state(0, h0, c0)
+            L.set_window(xi, ti)
+        L.forward()
+        loss = L.loss()
+        L.backward()
+        g = L.get_grads()
+        wi = L.get_window()
+        L.close()
+        return loss, g, wi
+
+    la, ga, wa = run(False)
+    lb, gb, wb = run(True)
+    assert la == lb and np.array_equal(ga, gb)
+    assert np.array_equal(wa[0][1:], wb[0][1:]) and np.array_equal(wa[1][1:], wb[1][1:])
+    fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
+    assert abs(lb - fw["loss_bits"]) <= LOSS_TOL * (S - 1)
+    bad = x.copy()
+    bad[2, 3, 7] = 0.5
+    L = lstm_hip.Lstm(N, S, B)
+    with pytest.raises(lstm_hip.LstmHipError, match="one-hot"):
+        L.set_inputs_dense(bad, tg)
+    L.close()
 
 
 def test_call_order_errors():
@@ -293,13 +359,22 @@ def test_device_resident_loop_follows_the_oracle_trainer(N, S, B, windows, oracl
     L.close()
 
 
-def test_free_running_trajectory_stays_near_the_oracle(oracle32):
-    """Same loop without re-synchronisation.  Trajectories separate (Adagrad's first steps are
-    +-lr*sign(d), so a rounding-level sign flip of a near-zero gradient moves a weight by 2*lr;
-    SURVEY 7 hard part 2): tight for the first windows, loose afterwards, averages agree."""
+FREE_RUN_K = 4.0  # HIP-vs-oracle distance allowed, in units of the distance between two correct CPU implementations
+
+
+def test_free_running_trajectory_stays_near_the_oracle(oracle32, oracle64):
+    """Same loop without re-synchronisation.  Trajectories of ANY two implementations separate (Adagrad's first steps are
+    +-lr*sign(d), so a rounding-level sign flip of a near-zero gradient moves a weight by 2*lr; SURVEY 7 hard part 2), so
+    the tolerance is calibrated, not guessed: tests/trajectory_util.py runs the oracle itself in float64 and from
+    parameters one ulp away (ten controls) and measures how far those correct implementations end up from the float32
+    oracle (tests/test_oracle_pinning.py::test_correct_implementations_drift_apart).  The HIP path must stay within
+    FREE_RUN_K = 4 x that distance, per window and in the late average, and within 1e-3 bits for the first windows."""
     import lstm_hip
+    import trajectory_util as tu
     N, S, B, windows, lr = 64, 10, 20, 60, 0.1
-    text = _synthetic_text(4000, seed=5)
+    text = tu.printable_text(4000, seed=5)
+    base, controls = tu.oracle_trajectories(oracle32, oracle64, text, N, S, B, windows, lr)
+    env_win, env_late = tu.envelope(base, controls, S)
     tr = oracle32.trainer(text, N, S, B, lr=lr, seed=1)
     tr.epoch_reset()
     L = lstm_hip.Lstm(N, S, B)
@@ -309,13 +384,15 @@ def test_free_running_trajectory_stays_near_the_oracle(oracle32):
     L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
     L.reset_window()
     got = L.train_windows(windows, lr)
-    want = np.array([tr.window() for _ in range(windows)])
     L.close()
-    d = np.abs(got - want)
-    assert d[:3].max() <= 1e-3, d[:3]
+    d = np.abs(got - base)
     per_char = d / (S - 1)
-    assert per_char.max() <= 0.25, per_char.max()                    # bits/char, any single window
-    assert abs(got[-20:].mean() - want[-20:].mean()) / (S - 1) <= 0.05  # bits/char, late average
+    late = abs(got[-20:].mean() - base[-20:].mean()) / (S - 1)
+    print(f"free-running: HIP per-window max {per_char.max():.5f} (controls {env_win:.5f}), late mean {late:.5f} "
+          f"(controls {env_late:.5f}) bits/char; first window over 1e-3 bits: {int(np.argmax(d > 1e-3)) if (d > 1e-3).any() else None}")
+    assert d[:10].max() <= 1e-3, d[:10]
+    assert per_char.max() <= FREE_RUN_K * env_win, (per_char.max(), env_win)
+    assert late <= FREE_RUN_K * env_late + 1e-4, (late, env_late)
 
 
 def _wrap(p, n, length, S):
@@ -376,6 +453,39 @@ def test_headline_shape_one_window_vs_oracle():
     np.testing.assert_allclose(np.sum(got["probs"][-1], axis=1), 1.0, atol=1e-5)
     np.testing.assert_allclose(g["W"].sum(axis=1), g["b"][:, 0], rtol=1e-3, atol=1e-3 * np.abs(g["b"]).max())
     assert abs(g["by"].sum()) <= 1e-2
+
+
+def test_reference_learning_rate_overflows_the_unshifted_softmax_on_both_sides():
+    """bench.py runs lr = 0.01, not the root file's 0.1 (R/lstm.cc:59).  The reason is a property of the reference's
+    arithmetic, not of the HIP path: with lr = 0.1 at the headline shape the logits outgrow expf's range and the softmax
+    WITHOUT a max shift (R/lstm.cc:199) returns inf/NaN.  Shown here on both sides from the same start: the CPU oracle
+    (which restates :199 literally) goes non-finite after a few dozen windows (window 37 in the build container), and the
+    HIP path does so within +-3 windows of it (the two trajectories are not bit-identical, see the free-running test).
+    Smaller shapes (hidden 512 with window 20, hidden 256) survive 300 windows in the oracle, so the full shape it is."""
+    import lstm_hip
+    from oracle_lib import Oracle
+    from bench import synthetic_text
+    N, S, B, lr, limit = 512, 100, 64, 0.1, 60
+    text = synthetic_text(1_000_000, seed=0)
+    tr = Oracle("f32_omp").trainer(text, N, S, B, lr=lr, seed=1)
+    tr.epoch_reset()
+    L = lstm_hip.Lstm(N, S, B)
+    L.set_params(tr.params.copy())
+    L.set_state(1, tr.h[1], tr.c[1])
+    L.set_text(text)
+    L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
+    L.reset_window()
+    got = L.train_windows(limit, lr)
+    L.close()
+    w_ref = None
+    for w in range(limit):
+        if not np.isfinite(tr.window()):
+            w_ref = w
+            break
+    bad = np.nonzero(~np.isfinite(got))[0]
+    assert w_ref is not None, "the oracle stayed finite: the lr = 0.1 overflow claim does not hold"
+    assert bad.size > 0, "the HIP path stayed finite where the oracle overflowed"
+    assert abs(int(bad[0]) - w_ref) <= 3, (int(bad[0]), w_ref)
 
 
 def test_rccl_path_with_a_single_rank_communicator():
@@ -534,10 +644,53 @@ def test_bf16_recurrence_matches_bf16_oracle(N, S, B, oracle32):
     assert gu.max_rel(got["h"][-1], fw["h"][S - 1]) < 0.5 * gu.max_rel(fw32["h"][S - 1], fw["h"][S - 1]) + 1e-6
 
 
-def test_bf16_flag_is_refused_where_unsupported():
+@pytest.mark.parametrize("bf16", [False, True])
+def test_configs4_full_size_window_vs_oracle(bf16):
+    """BASELINE configs[4] at full size -- hidden 1024, window 100, 16 streams per GPU (global batch 128 over 8 GPUs) -- one
+    whole window (99 steps of hand-off in each direction) against the oracle, in fp32 and in the bf16-recurrence mode
+    (oracle in the same mode).  Tolerances as in the small cases: fp32 2e-5 / 2e-4, bf16 2e-3 / 1e-2 of scale."""
+    import lstm_hip
+    from oracle_lib import Oracle
+    N, S, B = 1024, 100, 16
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=4, scale=0.02, empty=((1, 3),))
+    orc = Oracle("f32_omp")
+    orc.set_bf16_recurrence(bf16)
+    try:
+        fw = orc.forward(N, 256, S, B, P, xi, ti, h0, c0)
+        dref = orc.backward(N, 256, S, B, P, xi, ti, fw)
+    finally:
+        orc.set_bf16_recurrence(False)
+    got = _run_hip(lstm_hip, N, S, B, P, xi, ti, h0, c0, flags=lstm_hip.BF16_RECURRENCE if bf16 else 0)
+    act_tol, loss_tol, grad_tol = (2e-3, 1e-3, 1e-2) if bf16 else (ACT_TOL, LOSS_TOL, GRAD_TOL)
+    for t in (1, 2, S // 2, S - 2, S - 1):
+        for name in ("h", "c", "g"):
+            assert gu.max_rel(got[name][t - 1], fw[name][t]) <= act_tol, (name, t)
+    assert abs(got["loss"] - fw["loss_bits"]) <= loss_tol * (S - 1)
+    rep = gu.grads_report(got["grads"], dref, N)
+    assert max(rep.values()) <= grad_tol, rep
+
+
+def test_bf16_flag_is_refused_where_unsupported(oracle32):
     import lstm_hip
     with pytest.raises(lstm_hip.LstmHipError):
         lstm_hip.Lstm(64, 5, 8, flags=lstm_hip.BF16_RECURRENCE)   # N not a multiple of 128
+    # the bf16 backward recurrence runs 8-column groups, N/16 * ceil(B/8) workgroups that must be co-resident (one per CU
+    # in the fused form): 16 * 17 = 272 > 256 CUs is refused at create, before any allocation ...
+    with pytest.raises(lstm_hip.LstmHipError, match="co-resident"):
+        lstm_hip.Lstm(256, 5, 136, flags=lstm_hip.BF16_RECURRENCE)
+    # ... and the largest grid that fits (16 * 16 = 256) runs and matches the bf16 oracle
+    N, S, B = 256, 5, 128
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=5, scale=0.05)
+    oracle32.set_bf16_recurrence(True)
+    try:
+        fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
+        dref = oracle32.backward(N, 256, S, B, P, xi, ti, fw)
+    finally:
+        oracle32.set_bf16_recurrence(False)
+    got = _run_hip(lstm_hip, N, S, B, P, xi, ti, h0, c0, flags=lstm_hip.BF16_RECURRENCE)
+    assert gu.max_rel(got["h"][-1], fw["h"][S - 1]) <= 2e-3
+    rep = gu.grads_report(got["grads"], dref, N)
+    assert max(rep.values()) <= 1e-2, rep
 
 
 def test_last_step_loss_mode(oracle32):

@@ -230,3 +230,19 @@ def test_empty_target_column_is_faithful_not_a_gradient(oracle64):
                 dy[t, b, ti[t, b]] -= 1.0
     np.testing.assert_allclose(dP["by"][:, 0], dy[1:].sum(axis=(0, 1)), rtol=1e-12, atol=1e-14)
     assert abs(dy[2, 1].sum() - 1.0) < 1e-12  # the empty column back-propagates the whole distribution
+
+
+def test_correct_implementations_drift_apart(oracle32, oracle64):
+    """The control experiment behind the free-running GPU tolerance (tests/trajectory_util.py): the oracle in float64,
+    and in float32 from parameters one ulp away, against the float32 oracle over 60 windows at lr = 0.1.  All agree to
+    1e-3 bits per window at first; none of them keeps that up (so "1e-3 for the first 100 windows", SURVEY 8d's
+    proposal, is not a property of the algorithm), while the late averages stay within 0.005 bits/char."""
+    import trajectory_util as tu
+    N, S, B, windows, lr = 64, 10, 20, 60, 0.1
+    text = tu.printable_text(4000, seed=5)
+    base, controls = tu.oracle_trajectories(oracle32, oracle64, text, N, S, B, windows, lr)
+    for c in controls:
+        assert np.abs(c - base)[:10].max() <= 1e-3
+    per_win, late = tu.envelope(base, controls, S)
+    assert sum(np.abs(c - base).max() > 1e-3 for c in controls) >= len(controls) - 2
+    assert 1e-3 < per_win < 0.25 and late < 0.005, (per_win, late)

@@ -4,7 +4,7 @@ The first Adagrad steps move every touched weight by +-lr*sign(d) (m = d^2, R/ls
 difference in a near-zero gradient flips a weight by 2*lr and the trajectories of any two implementations that round
 differently separate (hard part 2).  The free-running parity test therefore cannot use a fixed small
 tolerance; it is calibrated against CONTROLS: the oracle itself run (a) in float64 from the same float32 start and
-(b) in float32 with a few parameters moved by one ulp.  Every control is a correct implementation of
+(b) in float32 with a few parameters, or all of them, moved by one ulp.  Every control is a correct implementation of
 OV/lstm_eigen_opt/lstm.cc:186-318; their distance from the float32 oracle is the yardstick for the HIP path.
 """
 import numpy as np
@@ -14,7 +14,7 @@ def printable_text(n, seed):
     return np.random.RandomState(seed).choice(np.arange(32, 127), size=n).astype(np.uint8)
 
 
-def oracle_trajectories(oracle32, oracle64, text, N, S, B, windows, lr, seed=1, n_ulp_controls=6):
+def oracle_trajectories(oracle32, oracle64, text, N, S, B, windows, lr, seed=1, n_ulp_controls=6, n_all_controls=3):
     """Returns (base, controls): window losses (bits, summed over S-1 steps) of the float32 oracle and of each control."""
     def fresh(orc):
         tr = orc.trainer(text, N, S, B, lr=lr, seed=seed)
@@ -36,6 +36,12 @@ def oracle_trajectories(oracle32, oracle64, text, N, S, B, windows, lr, seed=1, 
         idx = rs.choice(t.params.size, size=50, replace=False)
         p = t.params
         p[idx] = np.nextafter(p[idx], np.float32(np.inf if k % 2 else -np.inf))
+        controls.append(np.array([t.window() for _ in range(windows)]))
+    for k in range(n_all_controls):  # float32 arithmetic, EVERY parameter one ulp away in a random direction
+        t = fresh(oracle32)
+        rs = np.random.RandomState(7 + k)
+        p = t.params
+        p[:] = np.nextafter(p, np.where(rs.rand(p.size) < 0.5, np.float32(np.inf), np.float32(-np.inf)).astype(np.float32))
         controls.append(np.array([t.window() for _ in range(windows)]))
     return base, controls
 

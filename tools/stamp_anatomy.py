@@ -1,0 +1,80 @@
+"""Diagnostic: where does a step of each recurrence spend its cycles?  (LSTM_HIP_DEBUG_STAMPS builds, headline shape)
+
+  python tools/stamp_anatomy.py            # forward (data-as-flag) + backward with the default hand-off
+  LSTM_HIP_BWD_HANDOFF=flag python tools/stamp_anatomy.py
+
+Stamps are s_memtime values (shader cycles) of lane 0 of three waves of two workgroups; slot meanings are in
+persistent.hip (FSTAMP / BSTAMP).  A stamped build forbids overlaps the real kernel has: read the SHARES, not the length.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "eigen-lstm_amd"))
+sys.path.insert(0, ROOT)
+import lstm_hip  # noqa: E402
+from bench import synthetic_text  # noqa: E402
+
+N, S, B = 512, 100, 64
+L = lstm_hip.Lstm(N, S, B, flags=lstm_hip.DEBUG_STAMPS)
+L.set_params(lstm_hip.init_params(lstm_hip.MT19937Normal(1), N))
+text = synthetic_text(200000)
+L.set_text(text)
+L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
+L.train_windows(S + 10, 0.001)
+st = L.debug_stamps().astype(np.float64)  # [fwd wg0, fwd wg1, bwd wg0, bwd wg1][t][16]
+L.close()
+
+
+def show(title, rows):
+    print(title)
+    for name, v in rows:
+        print(f"   {name:58s} median {np.median(v):8.0f}   p10 {np.percentile(v, 10):8.0f}   p90 {np.percentile(v, 90):8.0f}")
+
+
+for wg in range(2):
+    s = st[wg]
+    t = np.arange(3, S - 1)          # steady steps; step t+1 follows step t
+    tot = s[t + 1, 0] - s[t, 0]
+    show(f"forward, workgroup {wg}: {np.median(tot):.0f} cycles per step (wave 0: MFMA + gating)", [
+        ("poll of h_{t-1} (own K-slice) until complete", s[t, 1] - s[t, 0]),
+        ("   polls issued", s[t, 7]),
+        ("128 MFMA 4x4x1", s[t, 2] - s[t, 1]),
+        ("partial sums to LDS + workgroup barrier", s[t, 3] - s[t, 2]),
+        ("K-slice fold (32 LDS reads) + gates + cell", s[t, 4] - s[t, 3]),
+        ("s_waitcnt vmcnt(0) ahead of the publish", s[t, 5] - s[t, 4]),
+        ("publish + reset + off-chain stores issued", s[t, 6] - s[t, 5]),
+        ("end of step -> next step's first stamp", s[t + 1, 0] - s[t, 6]),
+        ("wave 3 (MFMA only): poll", s[t, 9] - s[t, 8]),
+        ("   polls issued", s[t, 12]),
+        ("wave 3: MFMA", s[t, 10] - s[t, 9]),
+        ("wave 3: LDS write + wait at the barrier", s[t, 11] - s[t, 10]),
+        ("wave 3: barrier -> its next step", s[t + 1, 8] - s[t, 11]),
+    ])
+
+df = os.environ.get("LSTM_HIP_BWD_HANDOFF", "c")[0] == "f"
+for wg in (2, 3):
+    s = st[wg]
+    t = np.arange(S - 4, 3, -1)      # steps run S-1 .. 1; step t-1 follows step t
+    tot = s[t - 1, 0] - s[t, 0]
+    rows = []
+    if df:
+        rows += [("hint poll (one piece per producer wave)", s[t, 2] - s[t, 0]), ("   hint polls issued", s[t, 6] + 1),
+                 ("checked pipelined loads + 128 MFMA (attempts below)", s[t, 3] - s[t, 2]), ("   extra attempts", s[t, 7])]
+    else:
+        rows += [("counter poll + workgroup barrier", s[t, 1] - s[t, 0]),
+                 ("pipelined loads + 128 MFMA + fold to LDS", s[t, 3] - s[t, 1])]
+    rows += [
+        ("wait at the workgroup barrier", s[t, 4] - s[t, 3]),
+        ("K-slice fold (8 LDS reads) + elementwise + DPP transpose", s[t, 5] - s[t, 4]),
+        ("drain/publish/(signal) + stage -> next step's first stamp", s[t - 1, 0] - s[t, 5]),
+        ("wave 3 (MFMA, then dW table): start -> before barrier", s[t, 11] - s[t, 8]),
+        ("wave 3: wait at the barrier", s[t, 12] - s[t, 11]),
+        ("wave 3: dW update -> its next step", s[t - 1, 8] - s[t, 12]),
+        ("wave 5 (MFMA, then follower): start -> before barrier", s[t, 14] - s[t, 13]),
+        ("wave 5: wait at the barrier", s[t, 15] - s[t, 14]),
+        ("wave 5: output-layer work -> its next step", s[t - 1, 13] - s[t, 15]),
+    ]
+    show(f"backward ({'data-as-flag' if df else 'counters'}), workgroup {wg - 2}: {np.median(tot):.0f} cycles per step", rows)
