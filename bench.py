@@ -113,15 +113,7 @@ def cpu_baseline(N, S, B, text, lr, budget_s=20.0):
            "sample": f"{n1} window(s) of the same workload (N={N} S={S} B={B}) in {dt1:.1f} s, "
                      "oracle/lstm_ref.c -O3 -march=native, single thread like the reference build"}
     try:
-        cores = len(os.sched_getaffinity(0))
-        try:  # a container's CPU share, when the cgroup states one
-            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-            if quota != "max":
-                cores = max(1, min(cores, -(-int(quota) // int(period))))
-        except (OSError, ValueError):
-            pass
-        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-        vo, no, dto = _time_oracle("f32_omp", N, S, B, text, lr, budget_s / 2)
+        vo, no, dto = _time_oracle("f32_omp", N, S, B, text, lr, budget_s / 2)  # OMP_NUM_THREADS = this process's CPU share
         out["all_cores"] = {"value": vo, "cores": int(os.environ["OMP_NUM_THREADS"]),
                             "sample": f"{no} window(s) in {dto:.1f} s, same source with -fopenmp"}
     except Exception as e:  # the generous figure is optional; the single-thread one above is the baseline

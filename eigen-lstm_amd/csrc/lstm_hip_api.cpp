@@ -103,7 +103,8 @@ struct lstm_hip_ctx {
     float *P = nullptr, *dP = nullptr, *mem = nullptr;
     float4 *Ufwd = nullptr, *Ubwd = nullptr;
     float4 *Ubwd4 = nullptr; // weight image of the 4x4x1 backward form (kernels.hip, k_pack_U), when bwd_uses_m4
-    float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel, when fwd_uses_8col_form
+    float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel (fwd_uses_8col_form) or, fwd_cols4, of the 4-column one
+    int fwd_cols4 = 0;       // 1: forward recurrence on 4-column groups, two workgroups per CU (k_fwd_persistent5)
     float *Hx = nullptr;     // 8-column forward form: ring of hand-off slots (data-as-flag), sentinel-filled
     int ring_base = 0;       // slot of step 0 in the next launch
     float *DGx = nullptr;    // backward recurrence: the same kind of ring for dg
@@ -235,6 +236,10 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
         }
         RUN(K_FWD_PERSIST, fwd_persistent_bf16(h->Ufwd16, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi,
                                                h->cnt, h->abortp, h->fwd_epoch, N, S, B, fast, h->st));
+    } else if (h->Hx && h->fwd_cols4) {
+        RUN(K_FWD_PERSIST, fwd_persistent5(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
+                                           h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st, h->stamps));
+        h->ring_base = fwd_ring_advance(h->ring_base, S);
     } else if (h->Hx) {
         RUN(K_FWD_PERSIST, fwd_persistent4(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
                                            h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st, h->stamps));
@@ -251,7 +256,7 @@ int do_forward(lstm_hip_ctx *h) {
     const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
     if (!h->packed) {
         RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd4 ? nullptr : h->Ufwd, h->Ubwd4 ? nullptr : h->Ubwd, N, h->st, h->Ubwd4,
-                             h->Ufwd4)); // one image per direction is live
+                             h->Ufwd4, h->fwd_cols4)); // one image per direction is live
         h->packed = true;
     }
     h->n_dby_parts = softmax_parts(h->T);
@@ -375,7 +380,7 @@ int do_allreduce(lstm_hip_ctx *h) {
 
 int do_adagrad(lstm_hip_ctx *h, double lr) {
     RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
-                           h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4));
+                           h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, h->fwd_cols4));
     h->packed = true; // the U images were refreshed by the same launch
     h->packed16 = false;
     return 0;
@@ -416,10 +421,8 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
         return fail(LSTM_HIP_ENODEV, "device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName);
     HIP_TRY(hipSetDevice(cfg->device));
     // everything that can be refused is refused before the first allocation
-    const bool want_persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) &&
-                                 persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount, !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512);
     if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) {
-        if (!want_persistent || cfg->N % 128 != 0 || cfg->N > 1024)
+        if ((cfg->flags & LSTM_HIP_STEP_KERNELS) || cfg->N % 128 != 0 || cfg->N > 1024)
             return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE needs the persistent engine and N a multiple of 128, <= 1024 (N=%d, B=%d)", cfg->N, cfg->B);
         if (!persistent_supported_bf16(cfg->N, cfg->B, prop.multiProcessorCount, !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512))
             return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE: the bf16 recurrence grids for N=%d, B=%d are not co-resident on %d CUs "
@@ -489,6 +492,7 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
                     persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount, want_fused);
     h->bwd_cols = bwd_group_cols(cfg->N, cfg->B, prop.multiProcessorCount);
     if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) { // refusals: lstm_hip_create, before anything is allocated
+        h->persistent = true;                    // ... where the bf16 kernels' own grids were checked
         h->bf16 = true;
         h->bwd_cols = 8;
         ALLOC(h->Hb, S * B * N);
@@ -505,7 +509,9 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
             HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * bwd_ring_floats((int)N, (int)B)));
         }
     }
-    if (h->persistent && !h->bf16 && fwd_uses_8col_form((int)N, (int)B, prop.multiProcessorCount)) {
+    const char *ff = getenv("LSTM_HIP_FWD_COLS"); // "8": keep 8-column groups where 4-column groups would fit (A/B; per handle)
+    h->fwd_cols4 = h->persistent && !h->bf16 && !(ff && atoi(ff) == 8) && fwd_4col_form_fits((int)N, (int)B, prop.multiProcessorCount);
+    if (h->persistent && !h->bf16 && (h->fwd_cols4 || fwd_uses_8col_form((int)N, (int)B, prop.multiProcessorCount))) {
         ALLOC(h->Ufwd4, N * N);
         ALLOC(h->Hx, fwd_ring_floats((int)N, (int)B));
         HIP_TRY(hipMemset(h->Hx, 0xff, sizeof(float) * fwd_ring_floats((int)N, (int)B)));

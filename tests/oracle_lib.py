@@ -26,16 +26,37 @@ def build_oracle():
     return libs
 
 
+def cpu_share():
+    """Cores this process may really use: the affinity mask, cut to the cgroup's CPU quota when there is one (a GPU box
+    shows every host core but grants its containers a share; OpenMP's default of one thread per visible core then
+    oversubscribes the share many times over and its spinning barriers crawl)."""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 class Oracle:
     """One precision of the oracle.  kind: 'f32', 'f64' or 'f32_omp'."""
 
     def __init__(self, kind="f32"):
         build_oracle()
+        if kind.endswith("_omp"):
+            os.environ.setdefault("OMP_NUM_THREADS", str(cpu_share()))  # read by libgomp when the library loads
         self.kind = kind
         self.suf = "_f64" if kind == "f64" else "_f32"
         self.np_t = np.float64 if kind == "f64" else np.float32
         self.c_t = C.c_double if kind == "f64" else C.c_float
         self.lib = C.CDLL(os.path.join(ORACLE_DIR, f"liblstm_ref_{kind}.so"))
+        if kind.endswith("_omp"):  # also when libgomp was initialised before the variable was set
+            try:
+                C.CDLL("libgomp.so.1").omp_set_num_threads(int(os.environ["OMP_NUM_THREADS"]))
+            except (OSError, AttributeError, ValueError):
+                pass
         L = self.lib
         L.ref_rng_sizeof.restype = C.c_size_t
         self._fn("ref_param_count").restype = C.c_size_t

@@ -1,7 +1,7 @@
 // Probe: operand/broadcast semantics of v_mfma_f32_4x4x1_16b_f32 with CBSZ/ABID/BLGP on gfx950.
 // Model under test (lane = 4*block + i, block = 8x + 4y + z):
 //   A_block(x,y,z)[i] = a[lane(x, y, abid, i)]          (cbsz = 2: groups of 4 consecutive blocks share block `abid`;
-//                                                         cbsz = 3: groups of 8, abid = 0..7)
+//                                                         cbsz = 3: groups of 8, abid = 0..7; cbsz = 4: all 16, abid = 0..15)
 //   B_block(x,y,z)[j] = b[lane(blgp==1 ? 0 : 1, y, z, j)] (blgp = 1: lanes 0-31 -> 32-63; blgp = 2: lanes 32-63 -> 0-31)
 //   D[reg i][lane(block, j)] += A_block[i] * B_block[j]
 #include <hip/hip_runtime.h>
@@ -25,6 +25,7 @@ template <int CBSZ, int ABID, int BLGP> int run(const float *da, const float *db
                 int ablk = blk, bblk = blk;
                 if (CBSZ == 2) ablk = (blk & ~3) | ABID;
                 if (CBSZ == 3) ablk = (blk & ~7) | ABID;
+                if (CBSZ == 4) ablk = ABID; // all 16 blocks read block `abid`
                 if (BLGP == 1) bblk = blk & 7;
                 if (BLGP == 2) bblk = (blk & 7) | 8;
                 const float want = ha[4 * ablk + i] * hb[4 * bblk + j];
@@ -55,5 +56,8 @@ int main() {
     bad += run<3, 0, 0>(da, db, dd, ha, hb);
     bad += run<3, 5, 1>(da, db, dd, ha, hb);
     bad += run<3, 7, 2>(da, db, dd, ha, hb);
+    bad += run<4, 0, 0>(da, db, dd, ha, hb);
+    bad += run<4, 9, 0>(da, db, dd, ha, hb);
+    bad += run<4, 15, 0>(da, db, dd, ha, hb);
     return bad ? 1 : 0;
 }
