@@ -24,12 +24,10 @@ struct ParamLayout {
 // ---- recurrent weight repack (once per window, after Adagrad) -------------------------------
 // Ufwd[N/4][N/16][64] float4 : MFMA 16x16x4 A-fragments of U for the forward product
 // Ubwd[N/16][N/4][64] float4 : A-fragments of U^T for the backward product
-// Ubwd4 / Ufwd4 (optional): the 4x4x1 images of the 8-column backward / forward forms; fwd_cols4: Ufwd4 receives the
-// image of the 4-column forward form (k_fwd_persistent5) instead
+// Ubwd4 / Ufwd4 (optional): the 4x4x1 images of the 8-column backward / forward forms
 void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, float4 *Ubwd4 = nullptr,
-            float4 *Ufwd4 = nullptr, int fwd_cols4 = 0);
+            float4 *Ufwd4 = nullptr);
 bool fwd_uses_8col_form(int N, int B, int n_cus); // forward recurrence on 8-column groups (k_fwd_persistent4, Ufwd4 image)
-bool fwd_4col_form_fits(int N, int B, int n_cus); // ... on 4-column groups, two workgroups per CU (k_fwd_persistent5, Ufwd5 image)
 bool bwd_uses_m4(int N, int cols, bool bf16);     // backward recurrence on v_mfma_f32_4x4x1 (8-column groups, fp32, Ubwd4 image)
 
 // ---- baseline engine: one launch per timestep -----------------------------------------------
@@ -58,9 +56,6 @@ void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float
 size_t fwd_ring_floats(int N, int B);
 int fwd_ring_advance(int ring_base, int S);
 void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
-                     float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
-                     int poll_cfg, hipStream_t st, unsigned long long *stamps = nullptr);
-void fwd_persistent5(const float4 *Ufwd5, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
                      int poll_cfg, hipStream_t st, unsigned long long *stamps = nullptr);
 // gpart != null (8-column groups only): fused mode.  The recurrence then also produces DHy on the fly from
@@ -120,7 +115,7 @@ void dW_sums(const float *DG, int T, int G4, float *dW, float *db, void *scratch
 // ---- Adagrad over the flat block (R/lstm.cc:261-272; eps added in double, :25,46-48)
 // When Ufwd/Ubwd are given, the U block also refreshes both MFMA fragment images (fused pack_U).
 void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
-             hipStream_t st, float4 *Ubwd4 = nullptr, float4 *Ufwd4 = nullptr, int fwd_cols4 = 0);
+             hipStream_t st, float4 *Ubwd4 = nullptr, float4 *Ufwd4 = nullptr);
 
 // ---- window builder on the device (OV/lstm_eigen_opt/lstm.cc:190-213): x/target rings + flat copies,
 //      cursor advance, and the h/c carry (column 1 -> column 0).  Single workgroup.

@@ -62,20 +62,9 @@ __device__ __forceinline__ size_t ufwd4_index(int row, int k, int N) { // float 
     const int l = 32 * xp + 4 * (u & 7) + gate;
     return (((((((size_t)(u >> 4) * 8 + w) * 2 + ((u >> 3) & 1)) * (Kw / 32) + L) * 2 + eh) * 2 + (s >> 2)) * 64 + l) * 4 + (s & 3);
 }
-//   Ufwd5[kb][w][ab][l].r (the 4-column forward form, k_fwd_persistent5; stored through the same pointer as Ufwd4 when
-//        `fwd_cols4` is set): wave w of workgroup kb owns input indices [Kw*w, Kw*(w+1)), Kw = N/8; lane l = 4*unit + gate;
-//        = U[gate of unit 16*kb + unit][Kw*w + 4*ab + r]
-__device__ __forceinline__ size_t ufwd5_index(int row, int k, int N) { // float index of U[row][k] in Ufwd5
-    const int gate = row / N, u = row % N, Kw = N / 8, w = k / Kw, kk = k % Kw;
-    const int l = 4 * (u & 15) + gate;
-    return ((((size_t)(u >> 4) * 8 + w) * (Kw / 4) + (kk >> 2)) * 64 + l) * 4 + (kk & 3);
-}
-__device__ __forceinline__ size_t ufwd45_index(int row, int k, int N, int fwd_cols4) {
-    return fwd_cols4 ? ufwd5_index(row, k, N) : ufwd4_index(row, k, N);
-}
 __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, float4 *__restrict__ Ufwd,
                                                 float4 *__restrict__ Ubwd, float4 *__restrict__ Ubwd4,
-                                                float4 *__restrict__ Ufwd4, int N, int fwd_cols4) {
+                                                float4 *__restrict__ Ufwd4, int N) {
     const int G4 = 4 * N;
     const size_t nf4 = (size_t)N * N; // float4 count of each image (4N*N floats)
     const size_t total = ((Ubwd4 || Ufwd4) ? 3 : 2) * nf4;
@@ -93,10 +82,10 @@ __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, flo
             }
             if (Ufwd4 != nullptr) {
                 float *f4 = reinterpret_cast<float *>(Ufwd4);
-                f4[ufwd45_index(r + 0, k, N, fwd_cols4)] = p.x;
-                f4[ufwd45_index(r + 1, k, N, fwd_cols4)] = p.y;
-                f4[ufwd45_index(r + 2, k, N, fwd_cols4)] = p.z;
-                f4[ufwd45_index(r + 3, k, N, fwd_cols4)] = p.w;
+                f4[ufwd4_index(r + 0, k, N)] = p.x;
+                f4[ufwd4_index(r + 1, k, N)] = p.y;
+                f4[ufwd4_index(r + 2, k, N)] = p.z;
+                f4[ufwd4_index(r + 3, k, N)] = p.w;
             }
         } else if (e < nf4) {
             int l = (int)(e & 63);
@@ -121,11 +110,11 @@ __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, flo
         }
     }
 }
-void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, float4 *Ubwd4, float4 *Ufwd4, int fwd_cols4) {
+void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, float4 *Ubwd4, float4 *Ufwd4) {
     size_t n = ((Ubwd4 || Ufwd4) ? 3 : 2) * (size_t)N * N;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_pack_U, dim3(blocks), dim3(256), 0, st, U, Ufwd, Ubwd, Ubwd4, Ufwd4, N, fwd_cols4);
+    hipLaunchKernelGGL(k_pack_U, dim3(blocks), dim3(256), 0, st, U, Ufwd, Ubwd, Ubwd4, Ufwd4, N);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1048,7 +1037,7 @@ __device__ __forceinline__ float adagrad1(float p, float d, float &m, float lr) 
 __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const float *__restrict__ dP,
                                                  float *__restrict__ mem, size_t n4, float lr, size_t u_off4, int N,
                                                  float4 *__restrict__ Ufwd, float4 *__restrict__ Ubwd,
-                                                 float4 *__restrict__ Ubwd4, float4 *__restrict__ Ufwd4, int fwd_cols4) {
+                                                 float4 *__restrict__ Ubwd4, float4 *__restrict__ Ufwd4) {
     const size_t u_n4 = (size_t)N * N; // float4 count of U
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 p = reinterpret_cast<float4 *>(P)[i];
@@ -1074,10 +1063,10 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const fl
             }
             if (Ufwd4 != nullptr) {
                 float *f4 = reinterpret_cast<float *>(Ufwd4);
-                f4[ufwd45_index(r + 0, k, N, fwd_cols4)] = p.x;
-                f4[ufwd45_index(r + 1, k, N, fwd_cols4)] = p.y;
-                f4[ufwd45_index(r + 2, k, N, fwd_cols4)] = p.z;
-                f4[ufwd45_index(r + 3, k, N, fwd_cols4)] = p.w;
+                f4[ufwd4_index(r + 0, k, N)] = p.x;
+                f4[ufwd4_index(r + 1, k, N)] = p.y;
+                f4[ufwd4_index(r + 2, k, N)] = p.z;
+                f4[ufwd4_index(r + 3, k, N)] = p.w;
             }
             if (Ufwd == nullptr) continue;
             // Ufwd[jb][k4][l].i = U[(l&3)*N + 4*jb + ((l&15)>>2)][16*k4 + 4*(l>>4) + i]
@@ -1095,11 +1084,11 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const fl
     }
 }
 void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
-             hipStream_t st, float4 *Ubwd4, float4 *Ufwd4, int fwd_cols4) {
+             hipStream_t st, float4 *Ubwd4, float4 *Ufwd4) {
     const size_t n4 = n / 4; // the flat block is a multiple of 4 floats (M = 256, N % 16 == 0)
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adagrad, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4, fwd_cols4);
+    hipLaunchKernelGGL(k_adagrad, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4);
 }
 
 // ------------------------------------------------------------------------------------------------

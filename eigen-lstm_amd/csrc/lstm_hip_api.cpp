@@ -103,8 +103,7 @@ struct lstm_hip_ctx {
     float *P = nullptr, *dP = nullptr, *mem = nullptr;
     float4 *Ufwd = nullptr, *Ubwd = nullptr;
     float4 *Ubwd4 = nullptr; // weight image of the 4x4x1 backward form (kernels.hip, k_pack_U), when bwd_uses_m4
-    float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel (fwd_uses_8col_form) or, fwd_cols4, of the 4-column one
-    int fwd_cols4 = 0;       // 1: forward recurrence on 4-column groups, two workgroups per CU (k_fwd_persistent5)
+    float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel, when fwd_uses_8col_form
     float *Hx = nullptr;     // 8-column forward form: ring of hand-off slots (data-as-flag), sentinel-filled
     int ring_base = 0;       // slot of step 0 in the next launch
     float *DGx = nullptr;    // backward recurrence: the same kind of ring for dg
@@ -236,10 +235,6 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
         }
         RUN(K_FWD_PERSIST, fwd_persistent_bf16(h->Ufwd16, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi,
                                                h->cnt, h->abortp, h->fwd_epoch, N, S, B, fast, h->st));
-    } else if (h->Hx && h->fwd_cols4) {
-        RUN(K_FWD_PERSIST, fwd_persistent5(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
-                                           h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st, h->stamps));
-        h->ring_base = fwd_ring_advance(h->ring_base, S);
     } else if (h->Hx) {
         RUN(K_FWD_PERSIST, fwd_persistent4(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
                                            h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st, h->stamps));
@@ -256,7 +251,7 @@ int do_forward(lstm_hip_ctx *h) {
     const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
     if (!h->packed) {
         RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd4 ? nullptr : h->Ufwd, h->Ubwd4 ? nullptr : h->Ubwd, N, h->st, h->Ubwd4,
-                             h->Ufwd4, h->fwd_cols4)); // one image per direction is live
+                             h->Ufwd4)); // one image per direction is live
         h->packed = true;
     }
     h->n_dby_parts = softmax_parts(h->T);
@@ -380,7 +375,7 @@ int do_allreduce(lstm_hip_ctx *h) {
 
 int do_adagrad(lstm_hip_ctx *h, double lr) {
     RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
-                           h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, h->fwd_cols4));
+                           h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4));
     h->packed = true; // the U images were refreshed by the same launch
     h->packed16 = false;
     return 0;
@@ -509,9 +504,7 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
             HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * bwd_ring_floats((int)N, (int)B)));
         }
     }
-    const char *ff = getenv("LSTM_HIP_FWD_COLS"); // "8": keep 8-column groups where 4-column groups would fit (A/B; per handle)
-    h->fwd_cols4 = h->persistent && !h->bf16 && !(ff && atoi(ff) == 8) && fwd_4col_form_fits((int)N, (int)B, prop.multiProcessorCount);
-    if (h->persistent && !h->bf16 && (h->fwd_cols4 || fwd_uses_8col_form((int)N, (int)B, prop.multiProcessorCount))) {
+    if (h->persistent && !h->bf16 && fwd_uses_8col_form((int)N, (int)B, prop.multiProcessorCount)) {
         ALLOC(h->Ufwd4, N * N);
         ALLOC(h->Hx, fwd_ring_floats((int)N, (int)B));
         HIP_TRY(hipMemset(h->Hx, 0xff, sizeof(float) * fwd_ring_floats((int)N, (int)B)));

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2(const float4 *__restric
 // CBSZ = 3 / ABID = s makes all eight u-blocks of a half read h from slot s of the loaded register (one register = 8
 // values of k x 8 columns = 8 instructions), BLGP = 1 / 2 makes both x-halves read the weights from one half of the
 // weight register (2 values of k each).  Every lane carries data and no partial sums need folding across lanes.  K is
-// split over the 8 waves; waves 0 and 1 finish the 128 (unit, column) pairs.  N = 256*NKQ, weights Ufwd4 (k_pack_U).
+// split over waves 0-7; two further waves (8, 9) finish the 128 (unit, column) pairs.  N = 256*NKQ, weights Ufwd4.
 //
 // Hand-off: THE DATA IS THE FLAG (Guideline 16, recipe R2, with the tag folded into the value space) -- no counter, no
 // drain, no poll -> barrier -> load sequence.  h_t is published into a ring of HX_RING = 4 step slots Hx[slot][B][N]
@@ -409,7 +409,9 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2(const float4 *__restric
 // that these are its slots 1 and 2 (the two that no in-launch reset precedes).  The host fills the ring with the
 // sentinel once (and after an abort).  Step 1 reads the carry column H[0], written before the launch.
 // The time-batched products read the plain H, stored off the chain.  One workgroup barrier per step (the K-slice
-// reduction), `red` double-buffered by step parity.
+// reduction: waves 0-7 arrive with their partial sums written, waves 8-9 leave to fold them), `red` double-buffered by
+// step parity: a product wave writes red[t & 1] again in step t+2, after the barrier of step t+1, which the gating
+// waves join only after they have read step t's sums.
 //
 // XCD-local publish (speed only, checked every launch): when all workgroups of a column group run on ONE XCD, h_t can be
 // published with plain stores -- the lines stay in that XCD's L2, which serves the group's sc1 loads directly -- instead
@@ -429,48 +431,36 @@ __device__ __forceinline__ bool hx_ready(const float4 &v) {
 }
 __device__ __forceinline__ float hx_canon(float v) { return __float_as_uint(v) == HX_SENT ? __uint_as_float(0x7FC00000u) : v; }
 
-// stamp slots [workgroup 0 | gridDim.x/2][t][16]: wave 0 (MFMA + gating) 0-7, wave 3 (MFMA only) 8-12
+// stamp slots [workgroup 0 | gridDim.x/2][t][16]: wave 3 (MFMA) 8-12, wave 8 (gating) 0-7
 #define FSTAMP(wave, k)                                                                                        \
     if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
         stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = __builtin_amdgcn_s_memtime();
 #define FSTAMP_VAL(wave, k, v)                                                                                 \
     if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
         stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = (unsigned long long)(v);
+constexpr int FWD4_THREADS = 640; // waves 0-7: the product (K split eight ways); waves 8, 9: gates, cell, publish
 template <int NKQ, bool FAST, bool STAMP = false>
-__global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restrict__ Ufwd4, const float *__restrict__ W,
+__global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent4(const float4 *__restrict__ Ufwd4, const float *__restrict__ W,
                                                          const float *__restrict__ bias, float *H, float *__restrict__ C,
                                                          float *__restrict__ G, const int32_t *__restrict__ xi, float *Hx,
                                                          unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base,
                                                          int S, int B, int poll_cfg, unsigned long long *stamps = nullptr) {
-    constexpr int N = 256 * NKQ, G4 = 4 * N, Kw = N / 8, NL = Kw / 32, RS = 136;
-    __shared__ float red[2][8 * 4 * RS]; // [step parity][wave][gate][column*16 + unit]
+    constexpr int N = 256 * NKQ, G4 = 4 * N, Kw = N / 8, NL = Kw / 32;
+    // partial sums [step parity][wave][pair = column*16 + unit][gate]: the four gates of a pair side by side (16-byte reads)
+    __shared__ __attribute__((aligned(16))) float red[2][8 * 128 * 4];
     __shared__ int s_abort;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int NB3 = gridDim.x, NG = gridDim.y;
     const int lin_ = blockIdx.x + NB3 * blockIdx.y;
     const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
+    const bool gating = w >= 8; // wave-uniform role
     const int lx = l >> 5, lu = (l >> 2) & 7, li = l & 3; // MFMA role: lane = 32x + 4u + i
     const int mcol = 8 * g + 4 * lx + li, mcolc = mcol < B ? mcol : B - 1;
-    const int gc = (tid >> 4) & 7, gu = tid & 15; // gating role (waves 0, 1): tid = column*16 + unit
+    const int pair = tid & 127; // gating role: pair = column*16 + unit
+    const int gc = pair >> 4, gu = pair & 15;
     const int col = 8 * g + gc, colc = col < B ? col : B - 1;
     const int j = 16 * kb + gu;
 
-    float4 wq[2][NL][2][2];
-#pragma unroll
-    for (int ps = 0; ps < 2; ps++)
-#pragma unroll
-        for (int L = 0; L < NL; L++)
-#pragma unroll
-            for (int eh = 0; eh < 2; eh++)
-#pragma unroll
-                for (int sh = 0; sh < 2; sh++)
-                    wq[ps][L][eh][sh] = Ufwd4[(((((((size_t)kb * 8 + w) * 2 + ps) * NL + L) * 2 + eh) * 2 + sh) * 64) + l];
-    float bs[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
-    if (w < 2) {
-#pragma unroll
-        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
-        cprev = C[(size_t)colc * N + j];
-    }
     const __amdgpu_buffer_rsrc_t rH = make_rsrc(H, (size_t)S * N * B * sizeof(float));
     const __amdgpu_buffer_rsrc_t rHx = make_rsrc(Hx, (size_t)HX_RING * N * B * sizeof(float));
     unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
@@ -482,55 +472,57 @@ __global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restric
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // visible before anything this workgroup publishes
         }
     }
-    bool local_pub = false;
     const int poll_sleep = poll_cfg & 255, poll_first = (poll_cfg >> 8) & 255;
     __syncthreads();
 
-    for (int t = 1; t < S; t++) {
-        const int par = t & 1;
-        float wx[4] = {0.f, 0.f, 0.f, 0.f};
-        if (w < 2) {
-            const int x = xi[t * B + colc];
-            if (x >= 0) {
+    if (!gating) {
+        // ---------------- waves 0-7: h_{t-1} -> this wave's K-slice of U*h for 16 units x 8 columns ----------------
+        float4 wq[2][NL][2][2];
 #pragma unroll
-                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
-            }
-        }
-        float4 b[NL];
-        FSTAMP(0, 0) FSTAMP(3, 8)
-        int polls = 0;
-        if (t == 1) {
-            const int off = (int)((((size_t)mcolc) * N + Kw * w + 4 * lu) * sizeof(float));
+        for (int ps = 0; ps < 2; ps++)
 #pragma unroll
-            for (int i = 0; i < NL; i++) b[i] = ld_sc1(rH, off + 128 * i);
-        } else {
-            const int slot = (t - 1 + ring_base) & (HX_RING - 1);
-            const int off = (int)((((size_t)slot * B + mcolc) * N + Kw * w + 4 * lu) * sizeof(float));
-            if (w >= 2)
-                for (int i = 0; i < poll_first; i++) __builtin_amdgcn_s_sleep(1); // the other waves cannot be early
-            bool ok = false;
-            for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
-                bool good = true;
+            for (int L = 0; L < NL; L++)
 #pragma unroll
-                for (int i = 0; i < NL; i++) {
-                    b[i] = ld_sc1(rHx, off + 128 * i);
-                    good = good && hx_ready(b[i]);
+                for (int eh = 0; eh < 2; eh++)
+#pragma unroll
+                    for (int sh = 0; sh < 2; sh++)
+                        wq[ps][L][eh][sh] = Ufwd4[(((((((size_t)kb * 8 + w) * 2 + ps) * NL + L) * 2 + eh) * 2 + sh) * 64) + l];
+        for (int t = 1; t < S; t++) {
+            float4 b[NL];
+            FSTAMP(3, 8)
+            int polls = 0;
+            if (t == 1) {
+                const int off = (int)((((size_t)mcolc) * N + Kw * w + 4 * lu) * sizeof(float));
+#pragma unroll
+                for (int i = 0; i < NL; i++) b[i] = ld_sc1(rH, off + 128 * i);
+            } else {
+                const int slot = (t - 1 + ring_base) & (HX_RING - 1);
+                const int off = (int)((((size_t)slot * B + mcolc) * N + Kw * w + 4 * lu) * sizeof(float));
+                for (int i = 0; i < poll_first; i++) __builtin_amdgcn_s_sleep(1);
+                bool ok = false;
+                for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                    bool good = true;
+#pragma unroll
+                    for (int i = 0; i < NL; i++) {
+                        b[i] = ld_sc1(rHx, off + 128 * i);
+                        good = good && hx_ready(b[i]);
+                    }
+                    if (STAMP) polls = spins + 1;
+                    if (__all(good)) {
+                        ok = true;
+                        break;
+                    }
+                    if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    for (int i = 0; i < poll_sleep; i++) __builtin_amdgcn_s_sleep(1); // 64 cycles each
                 }
-                if (STAMP) polls = spins + 1;
-                if (__all(good)) {
-                    ok = true;
-                    break;
+                if (!ok && l == 0) {
+                    __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_abort = 1;
                 }
-                if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                for (int i = 0; i < poll_sleep; i++) __builtin_amdgcn_s_sleep(1); // 64 cycles each
             }
-            if (!ok && l == 0) {
-                __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_abort = 1;
-            }
-        }
-        FSTAMP(0, 1) FSTAMP(3, 9) FSTAMP_VAL(0, 7, polls) FSTAMP_VAL(3, 12, polls)
-        f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
+            FSTAMP(3, 9) FSTAMP_VAL(3, 12, polls)
+            // four independent accumulation chains: [pass][slot parity]
+            f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
 #define F4_HALF(av, q0, q1, s0, blgp)                                                   \
     c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q0.x, c00, 3, s0 + 0, blgp);          \
     c10 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, q1.x, c10, 3, s0 + 0, blgp);          \
@@ -544,27 +536,52 @@ __global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restric
     F4_HALF(av, wq[0][L][eh][0], wq[1][L][eh][0], 0, blgp)   \
     F4_HALF(av, wq[0][L][eh][1], wq[1][L][eh][1], 4, blgp)
 #pragma unroll
-        for (int i = 0; i < NL; i++) {
-            F4_STEP(b[i].x, i, 0, 1)
-            F4_STEP(b[i].y, i, 0, 2)
-            F4_STEP(b[i].z, i, 1, 1)
-            F4_STEP(b[i].w, i, 1, 2)
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            for (int i = 0; i < NL; i++) {
+                F4_STEP(b[i].x, i, 0, 1)
+                F4_STEP(b[i].y, i, 0, 2)
+                F4_STEP(b[i].z, i, 1, 1)
+                F4_STEP(b[i].w, i, 1, 2)
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #undef F4_STEP
 #undef F4_HALF
-        FSTAMP(0, 2) FSTAMP(3, 10)
-        float *rp = red[par];
+            FSTAMP(3, 10)
+            // lane (x, u, gate li), register r of pass ps: gate li of unit 8*ps + u for column 4x + r
+            float *rp = red[t & 1] + w * 512;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            rp[(w * 4 + li) * RS + (4 * lx + r) * 16 + lu] = c00[r] + c01[r];
-            rp[(w * 4 + li) * RS + (4 * lx + r) * 16 + 8 + lu] = c10[r] + c11[r];
+            for (int r = 0; r < 4; r++) {
+                rp[((4 * lx + r) * 16 + lu) * 4 + li] = c00[r] + c01[r];
+                rp[((4 * lx + r) * 16 + 8 + lu) * 4 + li] = c10[r] + c11[r];
+            }
+            __syncthreads();
+            if (s_abort) return;
+            FSTAMP(3, 11)
         }
-        __syncthreads();
-        if (s_abort) return;
-        FSTAMP(0, 3) FSTAMP(3, 11)
-
-        if (w < 2) {
+    } else {
+        // ---------------- waves 8, 9: fold the K-slices, gates, cell, publish h_t; one (unit, column) pair per lane -------
+        // These waves sit at the workgroup barrier while the product runs, so the fold starts the moment the last partial
+        // sum is in LDS.  (With the gating done by two of the product waves, those two were the last to every barrier:
+        // between publishing h_t and their next MFMA they alone issued the off-chain stores, the W gather and the poll;
+        // the other six waited 1 300-1 500 cycles a step at the barrier -- stamps of that form, DESIGN.md.)
+        float bs[4], cprev, wx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
+        cprev = C[(size_t)colc * N + j];
+        int xnext = xi[1 * B + colc]; // input byte of the NEXT step's column, fetched a step ahead of the W gather
+        bool local_pub = false;
+        for (int t = 1; t < S; t++) {
+            // W column of this step's input byte (R/lstm.cc:176 with a one-hot x): in flight while the product runs
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) wx[gt] = 0.f;
+            if (xnext >= 0) {
+#pragma unroll
+                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)xnext * G4 + gt * N + j];
+            }
+            if (t + 1 < S) xnext = xi[(t + 1) * B + colc];
+            FSTAMP(8, 0)
+            __syncthreads();
+            if (s_abort) return;
+            FSTAMP(8, 1)
             if (XCD_LOCAL && t == 2) { // every workgroup of the group has published h_1, hence its XCC id before it
                 unsigned mine = 0;
                 bool same = true;
@@ -576,28 +593,33 @@ __global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restric
                 if (l < NB3) same = same && mine == first;
                 local_pub = (XCD_FORCE_LOCAL || __all(same)) && NB3 <= 64;
             }
-            float pre[4];
+            const float *rp = red[t & 1] + pair * 4;
+            float4 uh = *reinterpret_cast<const float4 *>(rp);
 #pragma unroll
-            for (int gt = 0; gt < 4; gt++) {
-                float uh = rp[(0 * 4 + gt) * RS + tid];
-#pragma unroll
-                for (int ww = 1; ww < 8; ww++) uh += rp[(ww * 4 + gt) * RS + tid];
-                pre[gt] = (wx[gt] + uh) + bs[gt]; // R/lstm.cc:176
+            for (int ww = 1; ww < 8; ww++) {
+                const float4 v = *reinterpret_cast<const float4 *>(rp + ww * 512);
+                uh.x += v.x;
+                uh.y += v.y;
+                uh.z += v.z;
+                uh.w += v.w;
             }
-            const float ig = p_sigm<FAST>(pre[0]), og = p_sigm<FAST>(pre[1]), fg = p_sigm<FAST>(pre[2]); // :179
-            const float ug_ = p_tanh<FAST>(pre[3]);                                                       // :182
-            const float cv = p_tanh<FAST>(ig * ug_ + fg * cprev);                                         // :185-189
-            const float hv = og * cv;                                                                     // :192
+            const float pre0 = (wx[0] + uh.x) + bs[0], pre1 = (wx[1] + uh.y) + bs[1]; // R/lstm.cc:176
+            const float pre2 = (wx[2] + uh.z) + bs[2], pre3 = (wx[3] + uh.w) + bs[3];
+            const float ig = p_sigm<FAST>(pre0), og = p_sigm<FAST>(pre1), fg = p_sigm<FAST>(pre2); // :179
+            const float ug_ = p_tanh<FAST>(pre3);                                                 // :182
+            const float cv = p_tanh<FAST>(ig * ug_ + fg * cprev);                                 // :185-189
+            const float hv = og * cv;                                                             // :192
             cprev = cv;
+            // four consecutive units sit in the four lanes of a quad: gather them for one 16-byte store
             float4 h4;
             h4.x = dpp_f<0x00>(hv);
             h4.y = dpp_f<0x55>(hv);
             h4.z = dpp_f<0xAA>(hv);
             h4.w = dpp_f<0xFF>(hv);
-            FSTAMP(0, 4)
+            FSTAMP(8, 2)
             // the reset this wave issued a step ago (and every older store) has completed before h_t can be seen
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            FSTAMP(0, 5)
+            FSTAMP(8, 3)
             if ((gu & 3) == 0 && col < B) {
                 const float4 hp = {hx_canon(h4.x), hx_canon(h4.y), hx_canon(h4.z), hx_canon(h4.w)};
                 const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
@@ -621,207 +643,8 @@ __global__ __launch_bounds__(512) void k_fwd_persistent4(const float4 *__restric
                 gcp[3 * N] = ug_;
                 C[((size_t)t * B + col) * N + j] = cv;
             }
-            FSTAMP(0, 6)
+            FSTAMP(8, 4)
         }
-    }
-}
-#undef FSTAMP
-#undef FSTAMP_VAL
-
-// ------------------------------------------------------------------------------------------------
-// forward recurrence, 4-column form (N = 512): grid (N/16, ceil(B/4)), 512 threads, TWO workgroups per CU.
-//
-// Why: with one workgroup per CU a step is a chain of latencies -- publish -> L2 -> poll hit -> MFMA -> LDS fold ->
-// barrier -> gates -> publish -- and the matrix pipe idles through all of it but the MFMA part (28 % busy in round 1).
-// Column groups are independent recurrences, so halve them: a group is FOUR batch columns, a workgroup still owns 16
-// units (all of K over its 8 waves, weights in VGPRs), and each CU hosts two workgroups of two different groups, each
-// with its own copy of the weight rows (64 VGPRs per wave, 4 waves per SIMD x 128 registers).  While one group waits
-// for its h_t, the other group's MFMAs run: the hardware interleaves the two chains; nothing in the code does.
-//
-// MFMA: v_mfma_f32_4x4x1, block = unit (lane = 4*unit + j), CBSZ = 4 / ABID = ab: all sixteen unit-blocks read the four
-// columns of h[k] from block ab of the loaded register, so ONE 16-byte load per lane (64 values of k x 4 columns) feeds
-// the wave's 64 instructions:
-//   D[i][j] (+)= h[k = Kw*w + 4*ab + r][column 4g + i] * U[gate j of unit 16*kb + unit][k]      (r = register 0..3)
-// Weights Ufwd5 (k_pack_U, ufwd5_index).  Wave 0 finishes the 64 (unit, column) pairs.  Hand-off, ring, XCD-local
-// publish and stamps exactly as in k_fwd_persistent4; a group's 32 workgroups are again one XCD's worth (groups g and
-// g + 8 share an XCD).
-// ------------------------------------------------------------------------------------------------
-#define FSTAMP(wave, k)                                                                                        \
-    if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
-        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = __builtin_amdgcn_s_memtime();
-#define FSTAMP_VAL(wave, k, v)                                                                                 \
-    if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
-        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = (unsigned long long)(v);
-template <bool FAST, bool STAMP = false>
-__global__ __launch_bounds__(512, 4) void k_fwd_persistent5(const float4 *__restrict__ Ufwd5, const float *__restrict__ W,
-                                                            const float *__restrict__ bias, float *H, float *__restrict__ C,
-                                                            float *__restrict__ G, const int32_t *__restrict__ xi, float *Hx,
-                                                            unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base,
-                                                            int S, int B, int poll_cfg, unsigned long long *stamps = nullptr) {
-    constexpr int N = 512, G4 = 4 * N, Kw = N / 8, RS = 68; // RS: padded row of the partial-sum image (bank spread)
-    static_assert(Kw == 64, "one 16-byte load per lane covers the wave's K-slice");
-    __shared__ __attribute__((aligned(16))) float red[2][8 * 4 * RS]; // [step parity][wave][column][4*unit + gate]
-    __shared__ int s_abort;
-    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int NB5 = gridDim.x, NG = gridDim.y;
-    const int lin_ = blockIdx.x + NB5 * blockIdx.y;
-    const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
-    const int lb = l >> 2, li = l & 3; // MFMA role: lane = 4*block + i
-    const int mcol = 4 * g + li, mcolc = mcol < B ? mcol : B - 1;
-    // Gating role: EVERY wave finishes eight (unit, column) pairs on its lanes 0..7 -- unit quad w & 3, columns
-    // 2*(w >> 2) and 2*(w >> 2) + 1; lane = 4*column + unit so that a DPP quad holds four consecutive units.  (With one
-    // gating wave that wave is the last to every barrier: it alone does fold, gates, publish and the W gather between
-    // two MFMA phases -- 1 500 cycles of the other waves' barrier wait in the stamps of the 8-column form.)
-    const bool glane = l < 8;
-    const int gcl = 2 * (w >> 2) + ((l >> 2) & 1), gu = 4 * (w & 3) + (l & 3); // column within the group, unit within the workgroup
-    const int col = 4 * g + gcl, colc = col < B ? col : B - 1;
-    const int j = 16 * kb + gu;
-
-    float4 wq[16];
-#pragma unroll
-    for (int ab = 0; ab < 16; ab++) wq[ab] = Ufwd5[(((size_t)kb * 8 + w) * 16 + ab) * 64 + l];
-    float bs[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
-    int xnext = -1; // input byte of the NEXT step's column, fetched a step ahead (the W gather depends on it)
-    if (glane) {
-#pragma unroll
-        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
-        cprev = C[(size_t)colc * N + j];
-        xnext = xi[1 * B + colc];
-    }
-    const __amdgpu_buffer_rsrc_t rH = make_rsrc(H, (size_t)S * N * B * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rHx = make_rsrc(Hx, (size_t)HX_RING * N * B * sizeof(float));
-    unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
-    if (tid == 0) {
-        s_abort = 0;
-        if (XCD_LOCAL) {
-            __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // visible before anything this workgroup publishes
-        }
-    }
-    bool local_pub = false;
-    const int poll_sleep = poll_cfg & 255;
-    __syncthreads();
-
-    for (int t = 1; t < S; t++) {
-        const int par = t & 1;
-        // W column of this step's input byte (R/lstm.cc:176 with a one-hot x): issued now, consumed after the MFMAs
-        float wx[4] = {0.f, 0.f, 0.f, 0.f};
-        if (glane) {
-            const int x = xnext;
-            if (x >= 0) {
-#pragma unroll
-                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)x * G4 + gt * N + j];
-            }
-            if (t + 1 < S) xnext = xi[(t + 1) * B + colc];
-        }
-        float4 bv;
-        FSTAMP(0, 0) FSTAMP(3, 8)
-        int polls = 0;
-        if (t == 1) {
-            bv = ld_sc1(rH, (int)((((size_t)mcolc) * N + Kw * w + 4 * lb) * sizeof(float)));
-        } else {
-            const int slot = (t - 1 + ring_base) & (HX_RING - 1);
-            const int off = (int)((((size_t)slot * B + mcolc) * N + Kw * w + 4 * lb) * sizeof(float));
-            bool ok = false;
-            for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
-                bv = ld_sc1(rHx, off);
-                if (STAMP) polls = spins + 1;
-                if (__all(hx_ready(bv))) {
-                    ok = true;
-                    break;
-                }
-                if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                for (int i = 0; i < poll_sleep; i++) __builtin_amdgcn_s_sleep(1); // 64 cycles each
-            }
-            if (!ok && l == 0) {
-                __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_abort = 1;
-            }
-        }
-        FSTAMP(0, 1) FSTAMP(3, 9) FSTAMP_VAL(0, 7, polls) FSTAMP_VAL(3, 12, polls)
-        // four independent accumulation chains, one per register of the loaded fragment
-        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
-#define F5(ab)                                                              \
-    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv.x, wq[ab].x, c0, 4, ab, 0); \
-    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv.y, wq[ab].y, c1, 4, ab, 0); \
-    c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv.z, wq[ab].z, c2, 4, ab, 0); \
-    c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv.w, wq[ab].w, c3, 4, ab, 0);
-        F5(0) F5(1) F5(2) F5(3) F5(4) F5(5) F5(6) F5(7) F5(8) F5(9) F5(10) F5(11) F5(12) F5(13) F5(14) F5(15)
-#undef F5
-        FSTAMP(0, 2) FSTAMP(3, 10)
-        // lane (unit, gate j), register i = column i: one row of the image per (wave, column)
-        float *rp = red[par];
-#pragma unroll
-        for (int r = 0; r < 4; r++) rp[(w * 4 + r) * RS + l] = (c0[r] + c1[r]) + (c2[r] + c3[r]);
-        __syncthreads();
-        if (s_abort) return;
-        FSTAMP(0, 3) FSTAMP(3, 11)
-
-        if (XCD_LOCAL && t == 2) { // every workgroup of the group has published h_1, hence its XCC id before it
-            unsigned mine = 0;
-            bool same = true;
-            if (l < NB5) {
-                mine = __hip_atomic_load(xcc_tab + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                same = (mine >> 4) == epoch;
-            }
-            const unsigned first = __builtin_amdgcn_readfirstlane(mine);
-            if (l < NB5) same = same && mine == first;
-            local_pub = (XCD_FORCE_LOCAL || __all(same)) && NB5 <= 64;
-        }
-        float ig = 0.f, og = 0.f, fg = 0.f, ug_ = 0.f, cv = 0.f, hv = 0.f;
-        if (glane) {
-            // the four gates of (unit gu, column gcl) sit side by side in every wave's row gcl: one 16-byte read each
-            float4 pre4 = *reinterpret_cast<const float4 *>(rp + (0 * 4 + gcl) * RS + 4 * gu);
-#pragma unroll
-            for (int ww = 1; ww < 8; ww++) {
-                const float4 v = *reinterpret_cast<const float4 *>(rp + (ww * 4 + gcl) * RS + 4 * gu);
-                pre4.x += v.x;
-                pre4.y += v.y;
-                pre4.z += v.z;
-                pre4.w += v.w;
-            }
-            const float pre0 = (wx[0] + pre4.x) + bs[0], pre1 = (wx[1] + pre4.y) + bs[1]; // R/lstm.cc:176
-            const float pre2 = (wx[2] + pre4.z) + bs[2], pre3 = (wx[3] + pre4.w) + bs[3];
-            ig = p_sigm<FAST>(pre0), og = p_sigm<FAST>(pre1), fg = p_sigm<FAST>(pre2); // :179
-            ug_ = p_tanh<FAST>(pre3);                                                 // :182
-            cv = p_tanh<FAST>(ig * ug_ + fg * cprev);                                 // :185-189
-            hv = og * cv;                                                             // :192
-            cprev = cv;
-        }
-        float4 h4; // DPP needs every lane active: outside the branch
-        h4.x = dpp_f<0x00>(hv);
-        h4.y = dpp_f<0x55>(hv);
-        h4.z = dpp_f<0xAA>(hv);
-        h4.w = dpp_f<0xFF>(hv);
-        FSTAMP(0, 4)
-        // the reset this wave issued a step ago (and every older store) has completed before h_t can be seen
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        FSTAMP(0, 5)
-        if (glane && (l & 3) == 0 && col < B) {
-            const float4 hp = {hx_canon(h4.x), hx_canon(h4.y), hx_canon(h4.z), hx_canon(h4.w)};
-            const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
-                                 __uint_as_float(HX_SENT)};
-            const size_t e_pub = ((size_t)((t + ring_base) & (HX_RING - 1)) * B + col) * N + j;
-            const size_t e_rst = ((size_t)((t + 2 + ring_base) & (HX_RING - 1)) * B + col) * N + j;
-            if (XCD_LOCAL && local_pub) {
-                *reinterpret_cast<float4 *>(Hx + e_pub) = hp;
-                *reinterpret_cast<float4 *>(Hx + e_rst) = sent;
-            } else {
-                st_sc1(hp, rHx, (int)(e_pub * sizeof(float)));
-                st_sc1(sent, rHx, (int)(e_rst * sizeof(float)));
-            }
-            *reinterpret_cast<float4 *>(H + ((size_t)t * B + col) * N + j) = h4;
-        }
-        if (glane && col < B) {
-            float *gcp = G + ((size_t)t * B + col) * G4 + j;
-            gcp[0] = ig;
-            gcp[N] = og;
-            gcp[2 * N] = fg;
-            gcp[3 * N] = ug_;
-            C[((size_t)t * B + col) * N + j] = cv;
-        }
-        FSTAMP(0, 6)
     }
 }
 #undef FSTAMP
@@ -1704,7 +1527,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
 // host side
 // ------------------------------------------------------------------------------------------------
 size_t persistent_counter_bytes(int S, int B) {
-    const int NG = (B + 3) / 4; // the narrowest column groups in use (4-column forward form)
+    const int NG = (B + 7) / 8; // the narrowest column groups in use
     return (size_t)(S + 1) * NG * CNT_SLOTS * CNT_STRIDE * sizeof(unsigned);
 }
 
@@ -1721,14 +1544,10 @@ template <class K> static int blocks_per_cu(K kernel, int threads, size_t dyn_ld
 constexpr size_t DW_TABLE_BYTES = 257 * 64 * sizeof(float); // dynamic LDS of the fused backward form
 
 // which forward kernel serves a shape (one rule, no switches):
-//   4-column form (k_fwd_persistent5): N = 512, more than 8 streams, two workgroups per CU fit
 //   8-column form (k_fwd_persistent4): N = 256, 512, 1024, more than one 8-column group, one workgroup per CU fits
 //   second form (k_fwd_persistent2):   N = 128, 256, 512, 1024 otherwise (e.g. the evaluator's B = 1)
 //   first form (k_fwd_persistent):     every other multiple of 64
 static bool fwd_second_form(int N) { return N == 128 || N == 256 || N == 512 || N == 1024; }
-bool fwd_uses_4col_form(int N, int B, int n_cus) { // k_fwd_persistent5: two workgroups per CU
-    return N == 512 && B > 8 && (N / 16) * ((B + 3) / 4) <= 2 * n_cus;
-}
 bool fwd_uses_8col_form(int N, int B, int n_cus) {
     return (N == 256 || N == 512 || N == 1024) && B > 8 && (N / 16) * ((B + 7) / 8) <= n_cus;
 }
@@ -1739,7 +1558,6 @@ bool bwd_uses_m4(int N, int cols, bool bf16) { return cols == 8 && !bf16 && N % 
 // floats in one column group's partial gradient block [dW | dU | db | dWhy]
 size_t bwd_partial_floats(int N) { return (size_t)4 * N * 256 + (size_t)4 * N * N + (size_t)4 * N + (size_t)256 * N; }
 
-// the 4-column form is usable when its grid is co-resident at two workgroups per CU (fwd_4col_form_fits below)
 // All workgroups of a recurrence wait on each other, so its grid must be co-resident.  The occupancy API is asked about
 // exactly the instantiation that will be launched, with its dynamic LDS; it can over-report by one block per CU
 // (MI355X_MICROARCH.md, residency), so one is taken off wherever more than one is claimed.
@@ -1748,23 +1566,14 @@ static bool grid_fits(size_t grid, int per_cu, int n_cus) {
     if (per_cu > 8) per_cu = 8;
     return per_cu >= 1 && grid <= (size_t)per_cu * n_cus;
 }
-bool fwd_4col_form_fits(int N, int B, int n_cus) {
-    if (!fwd_uses_4col_form(N, B, n_cus)) return false;
-    // 512-thread workgroups at 128 VGPRs and 60 SGPRs: the register file admits exactly two per CU and the occupancy
-    // API's known over-count (SGPR-heavy 256-thread blocks, MI355X_MICROARCH.md) does not apply, so no margin is taken
-    return blocks_per_cu(k_fwd_persistent5<false>, 512) >= 2 && (size_t)(N / 16) * ((B + 3) / 4) <= (size_t)2 * n_cus;
-}
 bool persistent_supported(int N, int B, int n_cus, bool fused) {
     if (N % 64 != 0 || N > 1024) return false;
     int fb = 0, bb = 0;
     size_t fwd_grid = 0;
-    if (fwd_4col_form_fits(N, B, n_cus)) {
-        fwd_grid = 1; // checked above
-        fb = 1;
-    } else if (fwd_uses_8col_form(N, B, n_cus)) {
+    if (fwd_uses_8col_form(N, B, n_cus)) {
         fwd_grid = (size_t)(N / 16) * ((B + 7) / 8);
         switch (N / 256) {
-#define X(k) case k: fb = blocks_per_cu(k_fwd_persistent4<k, false>, 512); break;
+#define X(k) case k: fb = blocks_per_cu(k_fwd_persistent4<k, false>, FWD4_THREADS); break;
             X(1) X(2) X(4)
 #undef X
         }
@@ -1866,7 +1675,7 @@ int fwd_ring_advance(int ring_base, int S) { return (ring_base + S - 1) & (HX_RI
 void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
                      int poll_cfg, hipStream_t st, unsigned long long *stamps) {
-    const dim3 grid(N / 16, (B + 7) / 8), block(512);
+    const dim3 grid(N / 16, (B + 7) / 8), block(FWD4_THREADS);
     if (stamps != nullptr && N == 512) { // diagnostic build of the headline shape
         hipLaunchKernelGGL((k_fwd_persistent4<2, false, true>), grid, block, 0, st, Ufwd4, W, bias, H, C, G, xi, Hx, cnt, abortp,
                            epoch, ring_base, S, B, poll_cfg, stamps);
@@ -1881,21 +1690,6 @@ void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, flo
         X(1) X(2) X(4)
 #undef X
     }
-}
-
-void fwd_persistent5(const float4 *Ufwd5, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
-                     float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
-                     int poll_cfg, hipStream_t st, unsigned long long *stamps) {
-    const dim3 grid(N / 16, (B + 3) / 4), block(512);
-    if (stamps != nullptr)
-        hipLaunchKernelGGL((k_fwd_persistent5<false, true>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch,
-                           ring_base, S, B, poll_cfg, stamps);
-    else if (fast)
-        hipLaunchKernelGGL((k_fwd_persistent5<true>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch,
-                           ring_base, S, B, poll_cfg, nullptr);
-    else
-        hipLaunchKernelGGL((k_fwd_persistent5<false>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch,
-                           ring_base, S, B, poll_cfg, nullptr);
 }
 
 void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, float *H, unsigned short *Hb, float *C,

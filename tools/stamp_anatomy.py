@@ -37,21 +37,18 @@ def show(title, rows):
 for wg in range(2):
     s = st[wg]
     t = np.arange(3, S - 1)          # steady steps; step t+1 follows step t
-    tot = s[t + 1, 0] - s[t, 0]
-    show(f"forward, workgroup {wg}: {np.median(tot):.0f} cycles per step (wave 0: MFMA + gating)", [
-        ("poll of h_{t-1} (own K-slice) until complete", s[t, 1] - s[t, 0]),
-        ("   polls issued", s[t, 7]),
-        ("128 MFMA 4x4x1", s[t, 2] - s[t, 1]),
-        ("partial sums to LDS + workgroup barrier", s[t, 3] - s[t, 2]),
-        ("K-slice fold (32 LDS reads) + gates + cell", s[t, 4] - s[t, 3]),
-        ("s_waitcnt vmcnt(0) ahead of the publish", s[t, 5] - s[t, 4]),
-        ("publish + reset + off-chain stores issued", s[t, 6] - s[t, 5]),
-        ("end of step -> next step's first stamp", s[t + 1, 0] - s[t, 6]),
-        ("wave 3 (MFMA only): poll", s[t, 9] - s[t, 8]),
+    tot = s[t + 1, 8] - s[t, 8]
+    show(f"forward, workgroup {wg}: {np.median(tot):.0f} cycles per step", [
+        ("product wave 3: poll of h_{t-1} (own K-slice) until complete", s[t, 9] - s[t, 8]),
         ("   polls issued", s[t, 12]),
-        ("wave 3: MFMA", s[t, 10] - s[t, 9]),
-        ("wave 3: LDS write + wait at the barrier", s[t, 11] - s[t, 10]),
-        ("wave 3: barrier -> its next step", s[t + 1, 8] - s[t, 11]),
+        ("product wave 3: 128 MFMA 4x4x1", s[t, 10] - s[t, 9]),
+        ("product wave 3: partial sums to LDS + wait at the barrier", s[t, 11] - s[t, 10]),
+        ("gating wave 8: W gather issued -> barrier released", s[t, 1] - s[t, 0]),
+        ("gating wave 8: K-slice fold (8 x 16-byte LDS reads) + gates + cell", s[t, 2] - s[t, 1]),
+        ("gating wave 8: s_waitcnt vmcnt(0) ahead of the publish", s[t, 3] - s[t, 2]),
+        ("gating wave 8: publish + reset + off-chain stores issued", s[t, 4] - s[t, 3]),
+        ("barrier released -> h_t published (gating wave, on the chain)", s[t, 3] - s[t, 1]),
+        ("h_t published -> next barrier released (product waves, on the chain)", s[t + 1, 1] - s[t, 3]),
     ])
 
 df = os.environ.get("LSTM_HIP_BWD_HANDOFF", "c")[0] == "f"
