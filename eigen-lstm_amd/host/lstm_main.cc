@@ -26,6 +26,7 @@
 #include "matrix_io.h"
 #include "rng.h"
 
+#include <signal.h>
 #include <sys/time.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -353,8 +354,12 @@ int run_rank(const Options &o, int rank, int up, int down) {
             }
             i += chunk;
             done_windows += chunk;
-            if (lead && o.test_every > 0 && now() - last_test > o.test_every) // class_CUDA lstm.cc:186-188
-                test_and_log(epoch_loss / ((double)S * (double)i), (i * flops_per_iteration / std::pow(2.0, 30)) / (now() - t0));
+            // mid-epoch report (class_CUDA lstm.cc:186-188).  With several ranks the lead only has its own share of the loss
+            // (local surprisal sum / GLOBAL batch); the ranks exchange sums once per epoch, not here, so the running figure is
+            // the lead's share scaled by the rank count -- an estimate over its streams, labelled as what the reference prints
+            if (lead && o.test_every > 0 && now() - last_test > o.test_every)
+                test_and_log(epoch_loss * (double)o.gpus / ((double)S * (double)i),
+                             (i * flops_per_iteration / std::pow(2.0, 30)) / (now() - t0));
             if (lead && !o.quiet) {
                 const double t1 = now();
                 printf("%9.2f%% %9.2f GFlOP/s\r", 100.0 * (double)(i + S) / (double)length,
@@ -453,29 +458,46 @@ int main(int argc, char **argv) {
         down_w[r] = down[1];
         kids[r] = pid;
     }
+    signal(SIGPIPE, SIG_IGN); // a rank that died must show up as a failed write, not end the parent
     // relay the unique id, then one loss sum per epoch
     uint8_t id[LSTM_HIP_UNIQUE_ID_BYTES];
     if (read(up_r[0], id, sizeof(id)) != (ssize_t)sizeof(id)) die("rank 0 did not produce a unique id");
     for (int r = 0; r < o.gpus; r++)
         if (write(down_w[r], id, sizeof(id)) != (ssize_t)sizeof(id)) die("relay");
-    for (long e = 0; e < o.epochs; e++) {
+    bool relay_failed = false;
+    for (long e = 0; e < o.epochs && !relay_failed; e++) {
         double sum = 0.0;
-        bool ok = true;
         for (int r = 0; r < o.gpus; r++) {
             double v = 0.0;
-            if (read(up_r[r], &v, sizeof(v)) != (ssize_t)sizeof(v)) ok = false;
+            if (read(up_r[r], &v, sizeof(v)) != (ssize_t)sizeof(v)) relay_failed = true; // EOF: that rank is gone
             sum += v;
         }
-        if (!ok) break;
+        if (relay_failed) break;
         for (int r = 0; r < o.gpus; r++)
-            if (write(down_w[r], &sum, sizeof(sum)) != (ssize_t)sizeof(sum)) ok = false;
-        if (!ok) break;
+            if (write(down_w[r], &sum, sizeof(sum)) != (ssize_t)sizeof(sum)) relay_failed = true;
     }
-    int rc = 0;
-    for (int r = 0; r < o.gpus; r++) {
+    // Reap.  A rank that fails (a non-finite window, a hand-off time-out, a HIP error) leaves the others blocked inside the
+    // next all-reduce: as soon as the relay breaks or any child ends badly, the remaining children are terminated instead
+    // of waited for.
+    int rc = 0, live = o.gpus;
+    bool failed = relay_failed;
+    std::vector<bool> done(o.gpus, false);
+    while (live > 0) {
+        if (failed)
+            for (int r = 0; r < o.gpus; r++)
+                if (!done[r]) kill(kids[r], SIGTERM);
         int st = 0;
-        waitpid(kids[r], &st, 0);
-        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+        const pid_t p = waitpid(-1, &st, 0);
+        if (p < 0) break;
+        for (int r = 0; r < o.gpus; r++)
+            if (kids[r] == p && !done[r]) {
+                done[r] = true;
+                live--;
+                if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+                    rc = 1;
+                    failed = true;
+                }
+            }
     }
     return rc;
 }

@@ -432,6 +432,71 @@ def test_split_batch_gradients_sum_to_full_batch():
     assert max(rep.values()) <= 2e-5, rep
 
 
+def test_two_rank_data_parallel_lock_step_without_rccl():
+    """The data-parallel step on the HIP path, RCCL replaced by a host-side SUM: two handles on one device own half the
+    streams each (as two ranks would), their gradient blocks are summed on the host and written back to both
+    (= ncclAllReduce(SUM) of the flat block), both apply Adagrad.  Over 12 windows, in lock-step with a full-batch handle:
+    the two replicas stay bit-identical to each other, their losses add up to the full-batch loss, and their parameters
+    follow the full-batch handle's (re-synchronised after every window, as in the reference's own CPU-vs-GPU check)."""
+    import lstm_hip
+    N, S, B, lr, windows = 128, 10, 32, 0.05, 12
+    half = B // 2
+    rs = np.random.RandomState(5)
+    P0 = lstm_hip.init_params(lstm_hip.MT19937Normal(2), N)
+    h0 = (rs.randn(B, N) * 0.1).astype(np.float32)
+    c0 = (rs.randn(B, N) * 0.1).astype(np.float32)
+    F = lstm_hip.Lstm(N, S, B)
+    R = [lstm_hip.Lstm(N, S, half), lstm_hip.Lstm(N, S, half)]
+    cols = [np.arange(0, half), np.arange(half, B)]
+    F.set_params(P0)
+    F.set_state(0, h0, c0)
+    for r in range(2):
+        R[r].set_params(P0)
+        R[r].set_state(0, h0[cols[r]], c0[cols[r]])
+        R[r].set_global_batch(B)
+    for w in range(windows):
+        xi = rs.randint(0, 256, size=(S, B)).astype(np.int32)
+        ti = rs.randint(0, 256, size=(S, B)).astype(np.int32)
+        if w == 0:
+            xi[1, 3] = ti[1, 3] = -1  # an empty column on rank 0
+        F.set_window(xi, ti)
+        F.forward()
+        lf = F.loss()
+        F.backward()
+        gf = F.get_grads()
+        F.adagrad(lr)
+        lsum, gsum = 0.0, None
+        for r in range(2):
+            R[r].set_window(xi[:, cols[r]], ti[:, cols[r]])
+            R[r].forward()
+            lsum += R[r].loss()
+            R[r].backward()
+            g = R[r].get_grads()
+            gsum = g if gsum is None else gsum + g  # the all-reduce (SUM, not mean: OV/lstm_eigen_opt/lstm.cc:271,297-299)
+        for r in range(2):
+            R[r].set_params(gsum, lstm_hip.P_GRADS)
+            R[r].adagrad(lr)
+        assert abs(lsum - lf) <= 1e-4, (w, lsum, lf)
+        rep = gu.grads_report(gsum, gf, N)
+        assert max(rep.values()) <= 2e-5, (w, rep)
+        pa, pb, pf = R[0].get_params(), R[1].get_params(), F.get_params()
+        assert np.array_equal(pa, pb), w                                   # replicas never diverge
+        assert np.array_equal(R[0].get_params(lstm_hip.P_MEM), R[1].get_params(lstm_hip.P_MEM)), w
+        mask = np.abs(gf) > 1e-3 * np.abs(gf).max()
+        assert np.abs(pa[mask] - pf[mask]).max() <= 2e-4 * lr + 1e-6, w
+        # next window from identical state everywhere: parameters, Adagrad memory, carry (column 1 -> column 0)
+        mem = F.get_params(lstm_hip.P_MEM)
+        h1, c1 = F.get_state(1)
+        F.set_state(0, h1, c1)
+        for r in range(2):
+            R[r].set_params(pf)
+            R[r].set_params(mem, lstm_hip.P_MEM)
+            R[r].set_state(0, h1[cols[r]], c1[cols[r]])
+    F.close()
+    for r in range(2):
+        R[r].close()
+
+
 def test_headline_shape_one_window_vs_oracle():
     """BASELINE configs[2] (hidden 512, window 100, batch 64): one full window against the oracle
     (OpenMP build, same arithmetic as the serial one), plus size-independent properties:
