@@ -78,14 +78,16 @@ def kernel_flops(N, S, B, M=256, fused=True):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json:
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r2_pmc_traffic.json, else r1:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, gfx950 x2 read correction applied).  PMC
     collection cannot run inside this process, so the figure is the recorded one; null if absent."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-        return d["kernels"][kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return d["kernels"][kernel]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
 def _time_oracle(kind, N, S, B, text, lr, budget_s):

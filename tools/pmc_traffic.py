@@ -1,4 +1,4 @@
-"""profiles/r1_pmc_traffic.json from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE).
+"""profiles/r<N>_pmc_traffic.json from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE); last argument: output path.
 
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 3
@@ -16,6 +16,9 @@ NAMES = {"k_bwd_persistent": "bwd_persistent", "k_fwd_persistent": "fwd_persiste
          "k_gemm<false, false": "gemm_Y", "k_adagrad": "adagrad", "k_softmax_loss_dy": "softmax_loss_dy"}
 
 
+OUT = sys.argv[3] if len(sys.argv) > 3 else "profiles/r2_pmc_traffic.json"
+
+
 def means(path, counter):
     acc = defaultdict(list)
     with open(path) as f:
@@ -31,7 +34,7 @@ def means(path, counter):
 def main():
     fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
     out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 10 "
-                     "--warmup 3`, MI355X, round 1 final kernels; per-launch means; units KB as reported",
+                     "--warmup 3`, MI355X, round 2 kernels; per-launch means; units KB as reported",
            "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> hbm_read_bytes = "
                          "2*FETCH_SIZE*1024; WRITE_SIZE exact.  Calibrated earlier in the round on k_dW_segsum (reads DG once, "
                          "51.9 MB: FETCH_SIZE 25396 KB x2 = 52.0 MB) and on the dU slabs (8 x 4 MiB: WRITE_SIZE 32768 KB).",
@@ -39,7 +42,7 @@ def main():
     for k in fetch:
         out["kernels"][k] = {"FETCH_SIZE_KB": round(fetch[k], 1), "WRITE_SIZE_KB": round(write.get(k, 0.0), 1),
                              "hbm_bytes_per_launch": int(2 * fetch[k] * 1024 + write.get(k, 0.0) * 1024)}
-    json.dump(out, open("profiles/r1_pmc_traffic.json", "w"), indent=1)
+    json.dump(out, open(OUT, "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
 
 
