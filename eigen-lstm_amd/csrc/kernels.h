@@ -87,6 +87,9 @@ int gemm_pick_splits(int M, int Nn, int K);
 // the ordered fold of `splits` slabs
 // slab_stride: floats between consecutive slabs (0 = M*Nn, i.e. densely packed)
 void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st, size_t slab_stride = 0);
+// the split-K product without its fold (slabs densely packed, M*Nn floats each); returns the number of slabs written
+int gemm_slabs(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *slabs, int splits,
+               hipStream_t st);
 
 // ---- output layer elementwise: probs = exp(y+by)/sum ; loss ; dy = probs - onehot  (R/lstm.cc:195-207,225)
 // Y is [T cols][256] (column-major 256 x T) and is overwritten by dY; probs written to P.
@@ -114,8 +117,12 @@ void dW_sums(const float *DG, int T, int G4, float *dW, float *db, void *scratch
 
 // ---- Adagrad over the flat block (R/lstm.cc:261-272; eps added in double, :25,46-48)
 // When Ufwd/Ubwd are given, the U block also refreshes both MFMA fragment images (fused pack_U).
-void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
-             hipStream_t st, float4 *Ubwd4 = nullptr, float4 *Ufwd4 = nullptr);
+// gpart != null: the gradient is still in pieces -- `n_groups` partial blocks [dW | - | db | dWhy] (group_stride floats apart)
+// and, when slabs != null, `n_slabs` split-K slabs of dU; they are summed here in the order the separate folds use and the
+// sums are also stored to dP.  by_off: float offset of dby in the flat block (dby is final in dP).
+void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
+             hipStream_t st, float4 *Ubwd4 = nullptr, float4 *Ufwd4 = nullptr, const float *gpart = nullptr, int n_groups = 0,
+             size_t group_stride = 0, size_t by_off = 0, const float *slabs = nullptr, int n_slabs = 0, size_t slab_stride = 0);
 
 // ---- window builder on the device (OV/lstm_eigen_opt/lstm.cc:190-213): x/target rings + flat copies,
 //      cursor advance, and the h/c carry (column 1 -> column 0).  Single workgroup.

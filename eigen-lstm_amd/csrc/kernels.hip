@@ -613,6 +613,16 @@ void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const
     if (splits > 1) gemm_reduce_launch(slabs, splits, M, Nn, C, ldc, st);
 }
 
+// the split-K product without its fold: `splits` slabs of M*Nn floats (gemm_pick_splits's count; slab z covers k-chunk z).
+// Returns the number of slabs written (the K chunking can need fewer than asked for).
+int gemm_slabs(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *slabs, int splits,
+               hipStream_t st) {
+    int kchunk = (K + splits - 1) / splits;
+    kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
+    splits = (K + kchunk - 1) / kchunk;
+    gemm_launch(TA, TB, M, Nn, K, A, lda, B, ldb, slabs, M, kchunk, (size_t)M * Nn, 0, splits, st);
+    return splits;
+}
 void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st, size_t slab_stride) {
     gemm_reduce_launch(slabs, splits, M, Nn, C, ldc, st, slab_stride);
 }
@@ -1034,14 +1044,50 @@ __device__ __forceinline__ float adagrad1(float p, float d, float &m, float lr) 
 // The U block additionally refreshes the two MFMA fragment images (what k_pack_U builds), so the
 // forward of the next window needs no separate repack launch.  A float4 here is 4 consecutive gate
 // rows of one column k of U: one float4 of Ubwd, four scalars of Ufwd.
-__global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const float *__restrict__ dP,
+// FOLD: the gradient is not in dP yet but in the pieces the backward pass left -- the column groups' partial blocks of the
+// fused recurrence (dW, db, dWhy: `fold.n_groups` blocks `fold.group_stride` floats apart, laid out like the flat block) and
+// the split-K slabs of the dU product -- and is summed here, in the order gemm_fold / k_gemm_reduce use (bit-identical),
+// then also stored to dP.  Saves three reduction launches and a round trip of the sums (single-GPU loop only: an
+// all-reduce needs the summed block first).
+struct GradFold {
+    const float *gpart;  // null: no fold
+    int n_groups;
+    size_t group_stride; // floats
+    size_t by_off4;      // float4 index where dby starts (already final in dP)
+    const float *slabs;  // dU split-K slabs; null: dU is final in dP
+    int n_slabs;
+    size_t slab_stride; // floats
+};
+template <bool FOLD>
+__global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *__restrict__ dP,
                                                  float *__restrict__ mem, size_t n4, float lr, size_t u_off4, int N,
                                                  float4 *__restrict__ Ufwd, float4 *__restrict__ Ubwd,
-                                                 float4 *__restrict__ Ubwd4, float4 *__restrict__ Ufwd4) {
+                                                 float4 *__restrict__ Ubwd4, float4 *__restrict__ Ufwd4, GradFold fold) {
     const size_t u_n4 = (size_t)N * N; // float4 count of U
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 p = reinterpret_cast<float4 *>(P)[i];
-        const float4 d = reinterpret_cast<const float4 *>(dP)[i];
+        float4 d;
+        if (FOLD && i < fold.by_off4) {
+            const bool in_u = i >= u_off4 && i < u_off4 + u_n4;
+            if (in_u && fold.slabs == nullptr) {
+                d = reinterpret_cast<const float4 *>(dP)[i];
+            } else {
+                const float *src = in_u ? fold.slabs + 4 * (i - u_off4) : fold.gpart + 4 * i;
+                const size_t stride = in_u ? fold.slab_stride : fold.group_stride;
+                const int n = in_u ? fold.n_slabs : fold.n_groups;
+                d = *reinterpret_cast<const float4 *>(src);
+                for (int z = 1; z < n; z++) {
+                    const float4 q = *reinterpret_cast<const float4 *>(src + (size_t)z * stride);
+                    d.x += q.x;
+                    d.y += q.y;
+                    d.z += q.z;
+                    d.w += q.w;
+                }
+                reinterpret_cast<float4 *>(dP)[i] = d;
+            }
+        } else {
+            d = reinterpret_cast<const float4 *>(dP)[i];
+        }
         float4 m = reinterpret_cast<float4 *>(mem)[i];
         p.x = adagrad1(p.x, d.x, m.x, lr);
         p.y = adagrad1(p.y, d.y, m.y, lr);
@@ -1083,12 +1129,19 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, const fl
         }
     }
 }
-void adagrad(float *P, const float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
-             hipStream_t st, float4 *Ubwd4, float4 *Ufwd4) {
+void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
+             hipStream_t st, float4 *Ubwd4, float4 *Ufwd4, const float *gpart, int n_groups, size_t group_stride, size_t by_off,
+             const float *slabs, int n_slabs, size_t slab_stride) {
     const size_t n4 = n / 4; // the flat block is a multiple of 4 floats (M = 256, N % 16 == 0)
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adagrad, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4);
+    const GradFold fold{gpart, n_groups, group_stride, by_off / 4, slabs, n_slabs, slab_stride};
+    if (gpart != nullptr)
+        hipLaunchKernelGGL(k_adagrad<true>, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4,
+                           Ufwd4, fold);
+    else
+        hipLaunchKernelGGL(k_adagrad<false>, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4,
+                           Ufwd4, fold);
 }
 
 // ------------------------------------------------------------------------------------------------

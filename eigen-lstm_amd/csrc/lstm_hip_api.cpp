@@ -90,6 +90,8 @@ struct lstm_hip_ctx {
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr; // the early part of the gradient all-reduce runs here, beside the dU product on `st`
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    bool fold_pending = false;  // the backward pass left the gradient in pieces for Adagrad to sum (single-GPU loop)
+    int n_slabs_dU = 0;         // ... with this many dU slabs (0: dU is final in dP)
     bool in_loop = false;       // inside lstm_hip_train_windows: nobody reads the gradient block between backward and Adagrad
     bool early_reduced = false; // [dW] and [db | dWhy | dby] are already being all-reduced on st2 (ev_join marks the end)
     float *slabs_dU = nullptr; // split-K slabs of dU
@@ -319,7 +321,12 @@ int do_backward(lstm_hip_ctx *h) {
         RUN(K_GEMM_DWHY, gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256,
                               h->splits_dWhy, h->slabs, h->st));
     // dW, db                           R/lstm.cc:251-252
-    if (fused) { // accumulated per column group inside the recurrence: fold the groups in order
+    // Inside the single-GPU loop nobody reads the gradient block between here and Adagrad: the folds of the group
+    // partials and of the dU slabs are left to the Adagrad launch (do_adagrad), three launches fewer per window.
+    const bool defer_fold = fused && h->in_loop && !h->comm;
+    if (defer_fold) {
+        h->fold_pending = true;
+    } else if (fused) { // accumulated per column group inside the recurrence: fold the groups in order
         const int NGb = (B + h->bwd_cols - 1) / h->bwd_cols;
         const size_t psz = bwd_partial_floats(N);
         // b and Why are adjacent both in the flat block and in the partial blocks: one fold covers both
@@ -350,8 +357,14 @@ int do_backward(lstm_hip_ctx *h) {
         h->early_reduced = true;
     }
     // dU = DG * H[0..S-2]^T            R/lstm.cc:250
-    RUN(K_GEMM_DU, gemm(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->dP + h->pl.U, G4, h->splits_dU,
-                        h->slabs_dU, h->st));
+    if (defer_fold && h->splits_dU > 1)
+        RUN(K_GEMM_DU, h->n_slabs_dU = gemm_slabs(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->slabs_dU,
+                                                   h->splits_dU, h->st));
+    else {
+        h->n_slabs_dU = 0;
+        RUN(K_GEMM_DU, gemm(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->dP + h->pl.U, G4, h->splits_dU,
+                            h->slabs_dU, h->st));
+    }
     return 0;
 }
 
@@ -374,6 +387,14 @@ int do_allreduce(lstm_hip_ctx *h) {
 }
 
 int do_adagrad(lstm_hip_ctx *h, double lr) {
+    if (h->fold_pending) {
+        h->fold_pending = false;
+        const int NGb = (h->cfg.B + h->bwd_cols - 1) / h->bwd_cols;
+        RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
+                               h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, h->gpart, NGb, bwd_partial_floats(h->cfg.N),
+                               h->pl.by, h->n_slabs_dU > 0 ? h->slabs_dU : nullptr, h->n_slabs_dU,
+                               (size_t)4 * h->cfg.N * h->cfg.N));
+    } else
     RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
                            h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4));
     h->packed = true; // the U images were refreshed by the same launch
