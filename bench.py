@@ -168,7 +168,18 @@ def main():
     rdzv = dp.Rendezvous(rank, world, tag=os.environ.get("MASTER_PORT", "0") + "_" + os.environ.get("TORCHELASTIC_RUN_ID", "0"))
 
     text = synthetic_text(cfg["nbytes"], seed=0)
-    L = lstm_hip.Lstm(N, S, B, device=local_rank, flags=args.flags)
+    bf16_refused = None
+    try:
+        L = lstm_hip.Lstm(N, S, B, device=local_rank, flags=args.flags)
+    except lstm_hip.LstmHipError as e:
+        if not args.bf16:
+            raise
+        # the bf16 path refuses shapes whose persistent grids are not co-resident (e.g. hidden 1024 with 128 streams per
+        # GPU): measure the fp32 path instead and say so in the line
+        bf16_refused = str(e)
+        args.bf16 = False
+        args.flags &= ~128
+        L = lstm_hip.Lstm(N, S, B, device=local_rank, flags=args.flags)
     rng = lstm_hip.MT19937Normal(1)
     L.set_params(lstm_hip.init_params(rng, N))  # identical on every rank
     srng = lstm_hip.MT19937Normal(1000 + rank)
@@ -237,7 +248,7 @@ def main():
     if rank == 0:
         # the library fuses DHy / dWhy into the backward recurrence when it runs on 8-column groups (one workgroup per CU on
         # the 256 CUs of an MI355X) and hidden <= 512
-        fl = kernel_flops(N, S, B, fused=not (args.flags & 64) and N <= 512 and N % 64 == 0 and
+        fl = kernel_flops(N, S, B, fused=not (args.flags & (64 | 128)) and N <= 512 and N % 64 == 0 and
                           (N // 16) * ((B + 7) // 8) <= 256)
         mf = {k: v for k, v in kstats.items() if k in fl}
         if mf:
@@ -247,13 +258,12 @@ def main():
             ach = fl[dom] / avg_s / 1e12
             # bf16 recurrence mode: the two recurrences run on the bf16 pipe (dense peak 2500 TFLOP/s); the PMC traffic
             # file was collected for the fp32 kernels only
-            bf16_kernel = bool(args.flags & 128) and dom in ("fwd_persistent", "bwd_persistent")
+            bf16_kernel = bool(args.flags & 128)  # every MFMA kernel of the bf16 path runs on the bf16 pipe
             peak = 2500.0 if bf16_kernel else PEAK_FP32_MFMA_TFLOPS
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None if bf16_kernel else pmc_traffic(dom),
                         "avg_launch_us": round(avg_s * 1e6, 2), "flop_per_launch": fl[dom],
-                        "window_frac": round((24.0 * N * N + 6.0 * 256 * N) * (value / world) / 1e12
-                                             / PEAK_FP32_MFMA_TFLOPS, 4)}
+                        "window_frac": round((24.0 * N * N + 6.0 * 256 * N) * (value / world) / 1e12 / peak, 4)}
 
     if rank == 0:
         out = {
@@ -262,11 +272,14 @@ def main():
             "value": round(value, 1), "unit": "chars/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 recurrent MFMA (f32 accumulate, f32 elsewhere)" if args.flags & 128 else "f32",
+            "dtype": "bf16" if args.flags & 128 else "f32",
+            "dtype_note": ("bf16 MFMA operands in the two recurrent and the four time-batched products, f32 accumulate, f32 master "
+                           "weights / elementwise / Adagrad" if args.flags & 128 else
+                           ("bf16 path refused for this shape, measured in f32: " + bf16_refused if bf16_refused else None)),
             "data": ("FAKE GPU (plumbing test, not a measurement) " if getattr(lstm_hip, "FAKE", False) else "")
                     + f"synthetic ({len(text)} bytes, enwik6 order-0 byte statistics; random-init weights, seed 1)",
             "config": {"workload": f"{cfg['label']}; run as hidden={N} seq={S} batch={B}/GPU (global {B * world}), "
-                                   f"{'bf16 recurrent MFMA' if args.bf16 else 'fp32'}, {cfg['corpus']}-sized synthetic text "
+                                   f"{'bf16 MFMA path' if args.bf16 else 'fp32'}, {cfg['corpus']}-sized synthetic text "
                                    f"({len(text)} bytes), stride-1 windows from a full window, Adagrad lr=%g" % lr,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "engine": "step-kernels" if (args.flags & lstm_hip.STEP_KERNELS) else "default"},

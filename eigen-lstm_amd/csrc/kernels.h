@@ -50,6 +50,7 @@ void bwd_step(const float4 *Ubwd, const float *DGnext /*null at t=S-1*/, const f
 size_t persistent_counter_bytes(int S, int B);
 bool persistent_supported(int N, int B, int n_cus, bool fused);      // fused: dW/db/DHy/dWhy inside the backward recurrence
 bool persistent_supported_bf16(int N, int B, int n_cus, bool fused); // the bf16 recurrence's own kernels and grids
+int bwd_group_cols_bf16(int N, int B, int n_cus, bool fused);        // 8 where that grid is co-resident, else 16
 void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
                     const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B, bool fast,
                     hipStream_t st);
@@ -90,6 +91,16 @@ void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc,
 // the split-K product without its fold (slabs densely packed, M*Nn floats each); returns the number of slabs written
 int gemm_slabs(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *slabs, int splits,
                hipStream_t st);
+
+// ---- bf16 time-batched products (LSTM_HIP_BF16_RECURRENCE): C[m + ldc*n] = sum_k A[m][k] * B[n][k], fp32 accumulate on
+//      v_mfma_f32_32x32x16_bf16.  A, B: bfloat16, k contiguous (lda, ldb in elements, multiples of 8; 16-byte aligned
+//      bases), K a multiple of 64 (zero-padded images).  transpose_pack_bf16 builds such an image from a column-major fp32
+//      matrix whose COLUMNS are the contraction index: dst[r][k] = bf16(src[k*ld + r]), zero for K <= k < Kpad.
+void gemm_bf16(int M, int Nn, int K, const unsigned short *A, int lda, const unsigned short *B, int ldb, float *C, int ldc,
+               int splits, float *slabs, hipStream_t st);
+int gemm_bf16_pick_splits(int M, int Nn, int K);
+void transpose_pack_bf16(const float *src, int K, int R, int ld, unsigned short *dst, int Kpad, hipStream_t st);
+void pack_bf16(const float *src, size_t n, unsigned short *dst, hipStream_t st);
 
 // ---- output layer elementwise: probs = exp(y+by)/sum ; loss ; dy = probs - onehot  (R/lstm.cc:195-207,225)
 // Y is [T cols][256] (column-major 256 x T) and is overwritten by dY; probs written to P.

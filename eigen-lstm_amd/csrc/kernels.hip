@@ -628,6 +628,147 @@ void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc,
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 time-batched products (LSTM_HIP_BF16_RECURRENCE, BASELINE configs[4]): C[m + ldc*n] = sum_k A[m][k] * B[n][k],
+// fp32 accumulate, on v_mfma_f32_32x32x16_bf16.  Both operands are bfloat16 images with k CONTIGUOUS (k_transpose_pack_bf16
+// builds them from the fp32 column-major activations), so a lane's MFMA fragment -- 8 consecutive k of one row -- is one
+// 16-byte read.  Workgroup = 4 waves, tile 128 x 128 x 64 (each wave 64 x 64 = 2 x 2 MFMA tiles), LDS double-buffered
+// (rows padded to 144 bytes: conflict-free 16-byte fragment reads), next k-tile's global loads in flight during the
+// MFMAs.  The operands are swapped in the instruction so that the accumulator holds C^T fragments and the stores run
+// along m.  K must be a multiple of 64 (the packed images are zero-padded); split-K writes slabs like k_gemm.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int HBM_ = 128, HBN_ = 128, HBK_ = 64, HLD_ = 72; // tile and the padded LDS row (elements)
+__global__ __launch_bounds__(256) void k_gemm_bf16(int M, int Nn, int K, const unsigned short *__restrict__ A, int lda,
+                                                   const unsigned short *__restrict__ Bm, int ldb, float *__restrict__ C,
+                                                   int ldc, int kchunk, size_t slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short hl[]; // As[2][128*72] | Bs[2][128*72]
+    unsigned short *As = hl, *Bs = hl + 2 * HBM_ * HLD_;
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    const int m0 = blockIdx.x * HBM_, n0 = blockIdx.y * HBN_;
+    const int kbeg = blockIdx.z * kchunk, kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    C += (size_t)blockIdx.z * slab_stride;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+    const int srow = tid >> 3, sch = (tid & 7) * 8; // staging: 32 rows x 8 chunks of 8 elements per pass, 4 passes
+    uint4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int row = p * 32 + srow;
+            ra[p] = (m0 + row < M) ? *reinterpret_cast<const uint4 *>(A + (size_t)(m0 + row) * lda + k0 + sch) : uint4{0, 0, 0, 0};
+            rb[p] = (n0 + row < Nn) ? *reinterpret_cast<const uint4 *>(Bm + (size_t)(n0 + row) * ldb + k0 + sch) : uint4{0, 0, 0, 0};
+        }
+    };
+    auto lstore = [&](int stage) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int row = p * 32 + srow;
+            *reinterpret_cast<uint4 *>(As + (size_t)stage * HBM_ * HLD_ + row * HLD_ + sch) = ra[p];
+            *reinterpret_cast<uint4 *>(Bs + (size_t)stage * HBN_ * HLD_ + row * HLD_ + sch) = rb[p];
+        }
+    };
+    const int ntiles = (kend - kbeg) / HBK_;
+    if (ntiles <= 0) return;
+    gload(kbeg);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < ntiles) gload(kbeg + (kt + 1) * HBK_);
+        const unsigned short *Ac = As + (size_t)cur * HBM_ * HLD_ + (wm * 64 + (l & 31)) * HLD_ + 8 * (l >> 5);
+        const unsigned short *Bc = Bs + (size_t)cur * HBN_ * HLD_ + (wn * 64 + (l & 31)) * HLD_ + 8 * (l >> 5);
+#pragma unroll
+        for (int ks = 0; ks < HBK_ / 16; ks++) {
+            bf16x8_t af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                af[i] = *reinterpret_cast<const bf16x8_t *>(Ac + i * 32 * HLD_ + ks * 16);
+                bf[i] = *reinterpret_cast<const bf16x8_t *>(Bc + i * 32 * HLD_ + ks * 16);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+        }
+        if (kt + 1 < ntiles) lstore(cur ^ 1); // the other stage: its readers finished before the previous barrier
+        __syncthreads();
+    }
+    // D[row][col] of the swapped product = C[m = col][n = row]
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) {
+            const int m = m0 + wm * 64 + mi * 32 + (l & 31);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int n = n0 + wn * 64 + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                if (m < M && n < Nn) C[(size_t)n * ldc + m] = acc[mi][ni][r];
+            }
+        }
+}
+// splits > 1: slabs of M*Nn floats (ld = M) + ordered fold, as gemm().  K: multiple of 64.
+void gemm_bf16(int M, int Nn, int K, const unsigned short *A, int lda, const unsigned short *B, int ldb, float *C, int ldc,
+               int splits, float *slabs, hipStream_t st) {
+    if (splits < 1) splits = 1;
+    int kchunk = (K + splits - 1) / splits;
+    kchunk = ((kchunk + HBK_ - 1) / HBK_) * HBK_;
+    splits = (K + kchunk - 1) / kchunk;
+    float *out = splits > 1 ? slabs : C;
+    const int ldo = splits > 1 ? M : ldc;
+    const size_t stride = splits > 1 ? (size_t)M * Nn : 0;
+    const size_t lds = sizeof(unsigned short) * 2 * (HBM_ + HBN_) * HLD_;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_gemm_bf16, dim3((M + HBM_ - 1) / HBM_, (Nn + HBN_ - 1) / HBN_, splits), dim3(256), lds, st, M, Nn, K, A,
+                       lda, B, ldb, out, ldo, kchunk, stride);
+    if (splits > 1) gemm_reduce_launch(slabs, splits, M, Nn, C, ldc, st);
+}
+int gemm_bf16_pick_splits(int M, int Nn, int K) {
+    const int tiles = ((M + HBM_ - 1) / HBM_) * ((Nn + HBN_ - 1) / HBN_);
+    int splits = 1;
+    while (tiles * splits < 256 && K / (splits * 2) >= 4 * HBK_) splits *= 2; // fill the CUs, keep >= 4 k-tiles per split
+    return splits;
+}
+// dst[r][k] = bf16(src[k*ld + r]) for k < K, 0 for K <= k < Kpad: the k-contiguous image of a column-major fp32 matrix whose
+// columns are the contraction index (activations [t][b][rows]).  64 x 64 tiles through LDS, both sides coalesced.
+__global__ __launch_bounds__(256) void k_transpose_pack_bf16(const float *__restrict__ src, int K, int R, int ld,
+                                                             unsigned short *__restrict__ dst, int Kpad) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int k = k0 + ty * 16 + i, r = r0 + tx;
+        tile[ty * 16 + i][tx] = (k < K && r < R) ? src[(size_t)k * ld + r] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int r = r0 + ty * 16 + i, k = k0 + tx;
+        if (r < R && k < Kpad) dst[(size_t)r * Kpad + k] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][ty * 16 + i]);
+    }
+}
+void transpose_pack_bf16(const float *src, int K, int R, int ld, unsigned short *dst, int Kpad, hipStream_t st) {
+    hipLaunchKernelGGL(k_transpose_pack_bf16, dim3((R + 63) / 64, (Kpad + 63) / 64), dim3(256), 0, st, src, K, R, ld, dst, Kpad);
+}
+// dst[i] = bf16(src[i]) (same layout)
+__global__ __launch_bounds__(256) void k_pack_bf16(const float *__restrict__ src, size_t n, unsigned short *__restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = __builtin_bit_cast(unsigned short, (__bf16)src[i]);
+}
+void pack_bf16(const float *src, size_t n, unsigned short *dst, hipStream_t st) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_pack_bf16, dim3(blocks), dim3(256), 0, st, src, n, dst);
+}
+
+// ------------------------------------------------------------------------------------------------
 // softmax_loss_dy: one wave per output column (M = 256 = 64 lanes x float4).
 //   probs = exp(y + by) / sum  (no max shift)     R/lstm.cc:195-201
 //   surprisal = -log2(probs[target])              R/lstm.cc:204

@@ -99,6 +99,11 @@ struct lstm_hip_ctx {
     bool packed16 = false;
     unsigned short *Hb = nullptr, *DGb = nullptr; // bf16 hand-off copies of h and dg
     void *Ufwd16 = nullptr, *Ubwd16 = nullptr;    // bf16 fragment images of U
+    // bf16 operands of the four time-batched products, k contiguous (kernels.h, gemm_bf16): Why^T and Why; per window
+    // h^T [N][SBpad], dy^T [256][Tpad], dg^T [4N][Tpad] and dy [T][256]
+    unsigned short *WhyT_b = nullptr, *Why_b = nullptr, *Ht_b = nullptr, *dYt_b = nullptr, *DGt_b = nullptr, *dYb = nullptr;
+    int Tpad = 0, SBpad = 0;
+    bool why_packed = false;
     float *gpart = nullptr;    // per-column-group partial [dW|dU|db|dWhy] blocks of the fused backward recurrence
     int bwd_cols = 16;         // batch columns per backward-recurrence workgroup (8 or 16)
 
@@ -251,7 +256,7 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
 int do_forward(lstm_hip_ctx *h) {
     const int N = h->cfg.N, B = h->cfg.B, S = h->cfg.S, G4 = 4 * N;
     const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
-    if (!h->packed) {
+    if (!h->packed && !h->bf16) { // (the bf16 path packs its own images, launch_fwd_recurrence)
         RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd4 ? nullptr : h->Ufwd, h->Ubwd4 ? nullptr : h->Ubwd, N, h->st, h->Ubwd4,
                              h->Ufwd4)); // one image per direction is live
         h->packed = true;
@@ -268,6 +273,15 @@ int do_forward(lstm_hip_ctx *h) {
         }
     }
     // Y = Why * H[1..S-1]   (R/lstm.cc:195 for every step at once)
+    if (h->bf16) { // bf16 operands (Why rounded once per update, the recurrence's own bf16 copy of h), fp32 accumulate
+        if (!h->why_packed) {
+            RUN(K_PACK_U, (transpose_pack_bf16(h->P + h->pl.Why, N, 256, 256, h->WhyT_b, N, h->st),
+                           pack_bf16(h->P + h->pl.Why, (size_t)256 * N, h->Why_b, h->st)));
+            h->why_packed = true;
+        }
+        RUN(K_GEMM_Y, gemm_bf16(256, h->T, N, h->WhyT_b, N, h->Hb + (size_t)N * B, N, h->Y + (size_t)256 * B, 256, 1, nullptr,
+                                h->st));
+    } else
     RUN(K_GEMM_Y, gemm(false, false, 256, h->T, N, h->P + h->pl.Why, 256, h->H + (size_t)N * B, N,
                        h->Y + (size_t)256 * B, 256, 1, nullptr, h->st));
     RUN(K_SOFTMAX, softmax_loss_dy(h->Y + (size_t)256 * B, h->Pr + (size_t)256 * B, h->P + h->pl.by, h->ti + B,
@@ -287,7 +301,10 @@ int do_backward(lstm_hip_ctx *h) {
     h->dby_done = false;
     // fused mode: the backward recurrence produces DHy = Why^T * dY (R/lstm.cc:228) itself and accumulates dW, db, dWhy
     const bool fused = h->persistent && h->gpart != nullptr && h->bwd_cols == 8;
-    if (!fused)
+    if (h->bf16) { // DHy = Why^T * dY on bf16 operands: both already have the contraction index m contiguous
+        RUN(K_GEMM_DHY, (pack_bf16(dY, (size_t)T * 256, h->dYb, h->st),
+                         gemm_bf16(N, T, 256, h->Why_b, 256, h->dYb, 256, h->DHy + (size_t)N * B, N, 1, nullptr, h->st)));
+    } else if (!fused)
         RUN(K_GEMM_DHY, gemm(true, false, N, T, 256, h->P + h->pl.Why, 256, dY, 256, h->DHy + (size_t)N * B, N, 1, nullptr,
                              h->st));
     unsigned *cb = h->cnt + h->cnt_bytes / sizeof(unsigned);
@@ -300,7 +317,7 @@ int do_backward(lstm_hip_ctx *h) {
         if (h->bf16) {
             RUN(K_BWD_PERSIST, bwd_persistent(reinterpret_cast<const float4 *>(h->Ubwd16), h->DG, h->DHy, h->G, h->C, h->H,
                                               h->xi, fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp,
-                                              h->bwd_epoch, N, S, B, 8, h->st, nullptr, h->DGb));
+                                              h->bwd_epoch, N, S, B, h->bwd_cols, h->st, nullptr, h->DGb));
         } else {
             RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd4 ? h->Ubwd4 : h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi,
                                               fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp, h->bwd_epoch, N, S,
@@ -317,7 +334,14 @@ int do_backward(lstm_hip_ctx *h) {
         }
     }
     // dWhy = dY * H[1..]^T             R/lstm.cc:226
-    if (!fused)
+    if (h->bf16) {
+        // the contraction runs over the window's columns: k-contiguous bf16 images of dy, h and dg first (zero-padded to
+        // Tpad); dy_t pairs with h_t, i.e. column (t-1)*B+b of dY with column t*B+b of H: the h image shifted by B columns
+        RUN(K_GEMM_DWHY, (transpose_pack_bf16(dY, T, 256, 256, h->dYt_b, h->Tpad, h->st),
+                          transpose_pack_bf16(h->H, S * B, N, N, h->Ht_b, h->SBpad, h->st),
+                          gemm_bf16(256, N, h->Tpad, h->dYt_b, h->Tpad, h->Ht_b + B, h->SBpad, h->dP + h->pl.Why, 256,
+                                    h->splits_dWhy, h->slabs, h->st)));
+    } else if (!fused)
         RUN(K_GEMM_DWHY, gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256,
                               h->splits_dWhy, h->slabs, h->st));
     // dW, db                           R/lstm.cc:251-252
@@ -357,7 +381,12 @@ int do_backward(lstm_hip_ctx *h) {
         h->early_reduced = true;
     }
     // dU = DG * H[0..S-2]^T            R/lstm.cc:250
-    if (defer_fold && h->splits_dU > 1)
+    if (h->bf16) { // dg_t pairs with h_{t-1}: column (t-1)*B+b of both images
+        h->n_slabs_dU = 0;
+        RUN(K_GEMM_DU, (transpose_pack_bf16(h->DG + (size_t)G4 * B, T, G4, G4, h->DGt_b, h->Tpad, h->st),
+                        gemm_bf16(G4, N, h->Tpad, h->DGt_b, h->Tpad, h->Ht_b, h->SBpad, h->dP + h->pl.U, G4, h->splits_dU,
+                                  h->slabs_dU, h->st)));
+    } else if (defer_fold && h->splits_dU > 1)
         RUN(K_GEMM_DU, h->n_slabs_dU = gemm_slabs(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->slabs_dU,
                                                    h->splits_dU, h->st));
     else {
@@ -394,11 +423,14 @@ int do_adagrad(lstm_hip_ctx *h, double lr) {
                                h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, h->gpart, NGb, bwd_partial_floats(h->cfg.N),
                                h->pl.by, h->n_slabs_dU > 0 ? h->slabs_dU : nullptr, h->n_slabs_dU,
                                (size_t)4 * h->cfg.N * h->cfg.N));
-    } else
+    } else if (h->bf16) // the fp32 fragment images are not used by the bf16 path (its own are repacked by pack_U_bf16)
+        RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, nullptr, nullptr, h->st));
+    else
     RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
                            h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4));
-    h->packed = true; // the U images were refreshed by the same launch
+    h->packed = true; // the fp32 U images were refreshed by the same launch (the bf16 path has none)
     h->packed16 = false;
+    h->why_packed = false;
     return 0;
 }
 
@@ -440,9 +472,11 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
     if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) {
         if ((cfg->flags & LSTM_HIP_STEP_KERNELS) || cfg->N % 128 != 0 || cfg->N > 1024)
             return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE needs the persistent engine and N a multiple of 128, <= 1024 (N=%d, B=%d)", cfg->N, cfg->B);
-        if (!persistent_supported_bf16(cfg->N, cfg->B, prop.multiProcessorCount, !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512))
-            return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE: the bf16 recurrence grids for N=%d, B=%d are not co-resident on %d CUs "
-                                         "(8-column groups: N/16 * ceil(B/8) workgroups)", cfg->N, cfg->B, prop.multiProcessorCount);
+        if (cfg->B % 8 != 0)
+            return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE needs a multiple of 8 streams (16-byte aligned bf16 operand rows); B=%d", cfg->B);
+        if (!persistent_supported_bf16(cfg->N, cfg->B, prop.multiProcessorCount, false))
+            return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE: the bf16 recurrence grids for N=%d, B=%d are not co-resident on %d CUs",
+                        cfg->N, cfg->B, prop.multiProcessorCount);
     }
 
     lstm_hip_ctx *h = new lstm_hip_ctx();
@@ -486,6 +520,12 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     ALLOC(h->dby_part, (size_t)256 * softmax_parts(h->T));
     h->splits_dWhy = gemm_pick_splits(256, (int)N, h->T);
     h->splits_dU = gemm_pick_splits((int)G4, (int)N, h->T);
+    if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) {
+        h->Tpad = (h->T + 63) / 64 * 64;
+        h->SBpad = ((int)B + h->Tpad + 63) / 64 * 64;
+        h->splits_dWhy = gemm_bf16_pick_splits(256, (int)N, h->Tpad);
+        h->splits_dU = gemm_bf16_pick_splits((int)G4, (int)N, h->Tpad);
+    }
     ALLOC(h->slabs, (size_t)h->splits_dWhy * 256 * N);
     ALLOC(h->slabs_dU, (size_t)h->splits_dU * G4 * N);
     ALLOC(h->dw_scratch, dW_scratch_bytes(h->T, (int)G4));
@@ -503,18 +543,25 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     h->cnt_bytes = persistent_counter_bytes((int)S, (int)B);
     ALLOC(h->cnt, 2 * h->cnt_bytes / sizeof(unsigned));
     ALLOC(h->abortp, 4);
-    const bool want_fused = !(cfg->flags & LSTM_HIP_NO_FUSED_GRADS) && cfg->N <= 512; // larger N: one workgroup per CU no longer holds
+    // bf16 path: every product is a bf16 GEMM of its own, nothing is fused into the recurrence
+    const bool want_fused = !(cfg->flags & (LSTM_HIP_NO_FUSED_GRADS | LSTM_HIP_BF16_RECURRENCE)) && cfg->N <= 512; // larger N: one workgroup per CU no longer holds
     h->persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) &&                          // the dW table beside the weights
                     persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount, want_fused);
     h->bwd_cols = bwd_group_cols(cfg->N, cfg->B, prop.multiProcessorCount);
     if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) { // refusals: lstm_hip_create, before anything is allocated
         h->persistent = true;                    // ... where the bf16 kernels' own grids were checked
         h->bf16 = true;
-        h->bwd_cols = 8;
+        h->bwd_cols = bwd_group_cols_bf16(cfg->N, cfg->B, prop.multiProcessorCount, false);
         ALLOC(h->Hb, S * B * N);
         ALLOC(h->DGb, S * B * G4);
         HIP_TRY(hipMalloc(&h->Ufwd16, (size_t)8 * N * N));
         HIP_TRY(hipMalloc(&h->Ubwd16, (size_t)8 * N * N));
+        ALLOC(h->WhyT_b, 256 * N);
+        ALLOC(h->Why_b, 256 * N);
+        ALLOC(h->Ht_b, N * (size_t)h->SBpad);
+        ALLOC(h->dYt_b, (size_t)256 * h->Tpad);
+        ALLOC(h->DGt_b, G4 * (size_t)h->Tpad);
+        ALLOC(h->dYb, (size_t)h->T * 256);
     }
     if (h->persistent && bwd_uses_m4((int)N, h->bwd_cols, h->bf16)) {
         ALLOC(h->Ubwd4, N * N);
@@ -551,7 +598,7 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     if (h->st2) (void)hipStreamSynchronize(h->st2);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->Ubwd4, h->Ufwd4, h->Hx, h->DGx, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
-                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
+                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->WhyT_b, h->Why_b, h->Ht_b, h->dYt_b, h->DGt_b, h->dYb, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -572,7 +619,7 @@ int lstm_hip_set_params(lstm_hip_t *h, int which, const float *host_block) {
     if (!dst || !host_block) return fail(LSTM_HIP_EINVAL, "set_params: bad block id %d or null pointer", which);
     HIP_TRY(hipMemcpyAsync(dst, host_block, sizeof(float) * h->pl.total, hipMemcpyHostToDevice, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
-    if (which == 0) h->packed = h->packed16 = false;
+    if (which == 0) h->packed = h->packed16 = h->why_packed = false;
     return 0;
 }
 int lstm_hip_get_params(lstm_hip_t *h, int which, float *host_block) {

@@ -1609,7 +1609,26 @@ bool persistent_supported(int N, int B, int n_cus, bool fused) {
     }
     return grid_fits(fwd_grid, fb, n_cus) && grid_fits((size_t)(N / 16) * ((B + cols - 1) / cols), bb, n_cus);
 }
-// the bf16 recurrence launches other instantiations on other grids (8-column groups in the backward recurrence always)
+// the bf16 recurrence launches other instantiations on other grids: 8-column groups in the backward recurrence when they
+// are co-resident (bwd_group_cols_bf16), else 16-column groups two workgroups to a CU
+static int bwd_bf16_blocks(int N, int cols, bool fused) {
+    int bb = 0;
+    switch (N / 32) {
+#define X(k)                                                                                             \
+    case k:                                                                                              \
+        bb = cols == 16 ? blocks_per_cu(k_bwd_persistent<k, 16, false, false, true>, 512, 0)             \
+             : fused    ? blocks_per_cu(k_bwd_persistent<k, 8, true, false, true>, 512, DW_TABLE_BYTES)  \
+                        : blocks_per_cu(k_bwd_persistent<k, 8, false, false, true>, 512, 0);             \
+        break;
+        X(4) X(8) X(16) X(32)
+#undef X
+    }
+    return bb;
+}
+int bwd_group_cols_bf16(int N, int B, int n_cus, bool fused) {
+    if (grid_fits((size_t)(N / 16) * ((B + 7) / 8), bwd_bf16_blocks(N, 8, fused), n_cus)) return 8;
+    return 16;
+}
 bool persistent_supported_bf16(int N, int B, int n_cus, bool fused) {
     if (N % 128 != 0 || N > 1024) return false;
     int fb = 0, bb = 0;
@@ -1629,16 +1648,9 @@ bool persistent_supported_bf16(int N, int B, int n_cus, bool fused) {
 #undef X
         }
     }
-    switch (N / 32) {
-#define X(k)                                                                                             \
-    case k:                                                                                              \
-        bb = fused ? blocks_per_cu(k_bwd_persistent<k, 8, true, false, true>, 512, DW_TABLE_BYTES)       \
-                   : blocks_per_cu(k_bwd_persistent<k, 8, false, false, true>, 512, 0);                  \
-        break;
-        X(4) X(8) X(16) X(32)
-#undef X
-    }
-    return grid_fits(fwd_grid, fb, n_cus) && grid_fits((size_t)(N / 16) * ((B + 7) / 8), bb, n_cus);
+    const int cols = bwd_group_cols_bf16(N, B, n_cus, fused);
+    bb = bwd_bf16_blocks(N, cols, fused && cols == 8);
+    return grid_fits(fwd_grid, fb, n_cus) && grid_fits((size_t)(N / 16) * ((B + cols - 1) / cols), bb, n_cus);
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
@@ -1741,12 +1753,13 @@ void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float
         hipLaunchKernelGGL((k_bwd_persistent<__VA_ARGS__>), grid, block, lds, st, Ubwd, DG, DHy, G, C, H, xi, gpart, Why, dY, cnt, \
                            abortp, epoch, S, B, spread, stamps, DGb, DGx, ring_base);                                   \
     } while (0)
-    if (DGb != nullptr) { // bf16 recurrence: 8-column groups, 16x16x32 tiles, counter hand-off
+    if (DGb != nullptr) { // bf16 recurrence: 8- or 16-column groups, 16x16x32 tiles, counter hand-off
         switch (N / 32) {
-#define X(k)                                            \
-    case k:                                             \
-        if (fuse) BWD_GO(k, 8, true, false, true);      \
-        else BWD_GO(k, 8, false, false, true);          \
+#define X(k)                                                  \
+    case k:                                                   \
+        if (cols == 16) BWD_GO(k, 16, false, false, true);    \
+        else if (fuse) BWD_GO(k, 8, true, false, true);       \
+        else BWD_GO(k, 8, false, false, true);                \
         break;
             X(4) X(8) X(16) X(32)
 #undef X

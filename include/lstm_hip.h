@@ -48,9 +48,10 @@ extern "C" {
 #define LSTM_HIP_STEP_KERNELS 4u   /* one launch per timestep (baseline engine) instead of the persistent
                                       recurrence kernels */
 
-#define LSTM_HIP_BF16_RECURRENCE 128u /* bf16 MFMA in the two recurrent products (U and the h / dg hand-off rounded to
-                                      bfloat16, fp32 accumulate, fp32 master weights and everything else);
-                                      needs N % 128 == 0 */
+#define LSTM_HIP_BF16_RECURRENCE 128u /* the bf16 MFMA path (BASELINE configs[4]): bf16 operands, fp32 accumulate, in the two
+                                      recurrent products (U, and the h / dg hand-off) and in the four time-batched ones
+                                      (Why*h, Why^T*dy, dy*h^T, dg*h^T); fp32 master weights, biases, elementwise math,
+                                      dW/db/dby and Adagrad.  Needs N % 128 == 0, N <= 1024, B % 8 == 0 */
 #define LSTM_HIP_NO_FUSED_GRADS 64u  /* compute dU/dW/db after the backward recurrence (GEMM + sorted segment sums)
                                       instead of accumulating them inside it */
 #define LSTM_HIP_DEBUG_STAMPS 16u    /* diagnostic builds of both recurrences (N = 512, 8-column forms) that record

@@ -61,6 +61,11 @@
  * (W gather, biases, gates, output layer, every weight gradient, Adagrad on fp32 master weights) is unchanged. */
 static int g_bf16_recurrence = 0;
 void ref_set_bf16_recurrence(int on) { g_bf16_recurrence = on; }
+/* ... and of the four time-batched products as well (the complete "bf16 MFMA path" of configs[4]): y = Why*h, dWhy = dy*h^T,
+ * Why^T*dy and dU = dg*h_prev^T take bf16-rounded operands (the SAME rounded h, dg as the recurrence; dy and Why rounded
+ * once), accumulate in fp32.  Biases, dW/db/dby (sums, no products), the elementwise math and Adagrad stay fp32. */
+static int g_bf16_products = 0;
+void ref_set_bf16_products(int on) { g_bf16_products = on; }
 static inline float bf16_rne(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -213,6 +218,12 @@ void FN(ref_forward)(int N, int M, int S, int B, const REAL *P, const int32_t *x
         for (size_t i = 0; i < (size_t)G * N; i++) Ub[i] = (REAL)bf16_rne((float)p.U[i]);
     }
     const REAL *Urec = Ub ? Ub : p.U;
+    REAL *Whyb = NULL; /* bf16 products mode: Why rounded once */
+    if (g_bf16_products) {
+        Whyb = (REAL *)malloc(sizeof(REAL) * (size_t)M * N);
+        for (size_t i = 0; i < (size_t)M * N; i++) Whyb[i] = (REAL)bf16_rne((float)p.Why[i]);
+    }
+    const REAL *Whyf = Whyb ? Whyb : p.Why;
     for (int t = 1; t < S; t++) {
         REAL *gt = g + (size_t)t * G * B, *ht = h + (size_t)t * N * B, *ct = c + (size_t)t * N * B;
         const REAL *hp = h + (size_t)(t - 1) * N * B, *cp = c + (size_t)(t - 1) * N * B;
@@ -251,8 +262,8 @@ void FN(ref_forward)(int N, int M, int S, int B, const REAL *P, const int32_t *x
             REAL sum = 0;
             for (int m = 0; m < M; m++) pc[m] = 0;
             for (int k = 0; k < N; k++) {
-                const REAL hk = ht[(size_t)b * N + k];
-                const REAL *Wk = p.Why + (size_t)k * M;
+                const REAL hk = Whyb ? (REAL)bf16_rne((float)ht[(size_t)b * N + k]) : ht[(size_t)b * N + k];
+                const REAL *Wk = Whyf + (size_t)k * M;
                 for (int m = 0; m < M; m++) pc[m] += Wk[m] * hk;
             }
             for (int m = 0; m < M; m++) {
@@ -272,7 +283,7 @@ void FN(ref_forward)(int N, int M, int S, int B, const REAL *P, const int32_t *x
         }
         lb += (double)(surpr_sum / (REAL)B); /* opt:249 */
     }
-    free(surpr); free(surpn); free(Ub);
+    free(surpr); free(surpn); free(Ub); free(Whyb);
     if (loss_bits) *loss_bits = lb;
     if (loss_nats) *loss_nats = ln_;
 }
@@ -299,6 +310,16 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
         for (size_t i = 0; i < (size_t)G * N; i++) Ub[i] = (REAL)bf16_rne((float)p.U[i]);
     }
     const REAL *Urec = Ub ? Ub : p.U;
+    REAL *Whyb = NULL, *dyb = NULL, *hb = NULL, *hpb = NULL; /* bf16 products mode: rounded operand copies */
+    if (g_bf16_products) {
+        Whyb = (REAL *)malloc(sizeof(REAL) * (size_t)M * N);
+        for (size_t i = 0; i < (size_t)M * N; i++) Whyb[i] = (REAL)bf16_rne((float)p.Why[i]);
+        dyb = (REAL *)malloc(sizeof(REAL) * (size_t)M * B);
+        hb = (REAL *)malloc(sizeof(REAL) * (size_t)N * B);
+        hpb = (REAL *)malloc(sizeof(REAL) * (size_t)N * B);
+        if (!dgb) dgb = (REAL *)malloc(sizeof(REAL) * (size_t)G * B);
+    }
+    const REAL *Whyf = Whyb ? Whyb : p.Why;
     for (int t = S - 1; t > 0; t--) {
         const REAL *gt = g + (size_t)t * G * B, *ht = h + (size_t)t * N * B, *ct = c + (size_t)t * N * B;
         const REAL *hp = h + (size_t)(t - 1) * N * B, *cp = c + (size_t)(t - 1) * N * B;
@@ -308,14 +329,20 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
             int tk = ti[t * B + b];
             for (int m = 0; m < M; m++) dy[(size_t)b * M + m] = pt[(size_t)b * M + m] - (m == tk ? (REAL)1 : (REAL)0);
         }
+        if (dyb) {
+            for (size_t i = 0; i < (size_t)M * B; i++) dyb[i] = (REAL)bf16_rne((float)dy[i]);
+            for (size_t i = 0; i < (size_t)N * B; i++) hb[i] = (REAL)bf16_rne((float)ht[i]);
+            for (size_t i = 0; i < (size_t)N * B; i++) hpb[i] = (REAL)bf16_rne((float)hp[i]);
+        }
+        const REAL *dyp = dyb ? dyb : dy, *htp = hb ? hb : ht, *hpp = hpb ? hpb : hp; /* product operands */
         /* dWhy += dy * h^T ; dby += rowsum(dy)   (opt:271-272) */
 #pragma omp parallel for schedule(static)
         for (int k = 0; k < N; k++) {
             REAL tmp[256];
             for (int m = 0; m < M; m++) tmp[m] = 0;
             for (int b = 0; b < B; b++) {
-                const REAL hk = ht[(size_t)b * N + k];
-                for (int m = 0; m < M; m++) tmp[m] += dy[(size_t)b * M + m] * hk;
+                const REAL hk = htp[(size_t)b * N + k];
+                for (int m = 0; m < M; m++) tmp[m] += dyp[(size_t)b * M + m] * hk;
             }
             for (int m = 0; m < M; m++) d.Why[(size_t)k * M + m] += tmp[m];
         }
@@ -329,7 +356,7 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
         for (int b = 0; b < B; b++)
             for (int k = 0; k < N; k++) {
                 REAL acc = 0;
-                for (int m = 0; m < M; m++) acc += p.Why[(size_t)k * M + m] * dy[(size_t)b * M + m];
+                for (int m = 0; m < M; m++) acc += Whyf[(size_t)k * M + m] * dyp[(size_t)b * M + m];
                 dh[(size_t)b * N + k] = acc + dhnext[(size_t)b * N + k];
             }
         for (int b = 0; b < B; b++) {
@@ -348,15 +375,19 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
                 dgc[3 * N + j] = (dcv * gc[j]) * tanh_prime(gc[3 * N + j]);         /* du */
             }
         }
+        /* the rounded dg serves the dU product (products mode) and the recurrent product (recurrence mode) alike */
+        if (dgb)
+            for (size_t i = 0; i < (size_t)G * B; i++) dgb[i] = (REAL)bf16_rne((float)dg[i]);
+        const REAL *dgprod = g_bf16_products ? dgb : dg;
         /* dU += dg * h_prev^T ; dW += dg * x^T ; db += rowsum(dg)   (opt:297-299) */
 #pragma omp parallel for schedule(static)
         for (int k = 0; k < N; k++) {
             REAL *tmp = utmp + (size_t)k * G; /* per-k scratch row (thread-private under OpenMP) */
             for (int r = 0; r < G; r++) tmp[r] = 0;
             for (int b = 0; b < B; b++) {
-                const REAL hk = hp[(size_t)b * N + k];
-                const REAL *dgb = dg + (size_t)b * G;
-                for (int r = 0; r < G; r++) tmp[r] += dgb[r] * hk;
+                const REAL hk = hpp[(size_t)b * N + k];
+                const REAL *dgc2 = dgprod + (size_t)b * G;
+                for (int r = 0; r < G; r++) tmp[r] += dgc2[r] * hk;
             }
             for (int r = 0; r < G; r++) d.U[(size_t)k * G + r] += tmp[r];
         }
@@ -371,9 +402,7 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
             d.b[r] += acc;
         }
         /* dhnext = U^T * dg ; dcnext = dc .* f   (opt:302-303) */
-        if (dgb)
-            for (size_t i = 0; i < (size_t)G * B; i++) dgb[i] = (REAL)bf16_rne((float)dg[i]);
-        const REAL *dgrec = dgb ? dgb : dg;
+        const REAL *dgrec = g_bf16_recurrence ? dgb : dg;
 #pragma omp parallel for schedule(static)
         for (int b = 0; b < B; b++)
             for (int k = 0; k < N; k++) {
@@ -386,6 +415,7 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
                 dcnext[(size_t)b * N + j] = dc[(size_t)b * N + j] * gt[(size_t)b * G + 2 * N + j];
     }
     free(dy); free(dh); free(dc); free(dg); free(dhnext); free(dcnext); free(utmp); free(Ub); free(dgb);
+    free(Whyb); free(dyb); free(hb); free(hpb);
 }
 
 /* m += d.*d ; p -= lr * d ./ sqrt(m + eps)   R/lstm.cc:261-272, over the whole flat block */

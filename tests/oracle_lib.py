@@ -79,6 +79,11 @@ class Oracle:
         """bf16 operands (RNE) in the two recurrent products, fp32 accumulate (BASELINE configs[4] semantics)."""
         self.lib.ref_set_bf16_recurrence(1 if on else 0)
 
+    def set_bf16_products(self, on):
+        """bf16 operands also in the four time-batched products (y, dWhy, Why^T*dy, dU): with set_bf16_recurrence(True)
+        this is the complete bf16 MFMA path of BASELINE configs[4]."""
+        self.lib.ref_set_bf16_products(1 if on else 0)
+
     # ---- RNG -------------------------------------------------------------------------------
     def rng(self, seed):
         buf = C.create_string_buffer(self.lib.ref_rng_sizeof())

@@ -683,24 +683,26 @@ def test_create_destroy_does_not_leak():
 
 @pytest.mark.parametrize("N,S,B", [(128, 6, 8), (256, 10, 24), (512, 12, 64), (1024, 4, 16)])
 def test_bf16_recurrence_matches_bf16_oracle(N, S, B, oracle32):
-    """LSTM_HIP_BF16_RECURRENCE (BASELINE configs[4] semantics: bf16 MFMA in the recurrent products, fp32
-    accumulate and fp32 everything else) against the oracle in the same mode (operands rounded to bfloat16,
-    round-to-nearest-even).  Both sides round the same values, so the only extra divergence over the fp32 case
+    """LSTM_HIP_BF16_RECURRENCE (BASELINE configs[4] semantics: bf16 MFMA operands in the two recurrent and the four
+    time-batched products, fp32 accumulate and fp32 everything else) against the oracle in the same mode (those operands
+    rounded to bfloat16, round-to-nearest-even).  Both sides round the same values, so the only extra divergence over the fp32 case
     is an operand landing on the other side of a bf16 rounding boundary (1 bf16 ulp = 2^-8 relative, on one of N
     terms).  Tolerances: activations 2e-3 of scale, loss 1e-3*(S-1) bits, gradients 1e-2 of scale per tensor
     (SURVEY 8d proposes 2e-2 for bf16 inputs)."""
     import lstm_hip
     P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=N + B, scale=0.05, empty=((1, 0),))
     oracle32.set_bf16_recurrence(True)
+    oracle32.set_bf16_products(True)
     try:
         fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
         dref = oracle32.backward(N, 256, S, B, P, xi, ti, fw)
     finally:
         oracle32.set_bf16_recurrence(False)
+        oracle32.set_bf16_products(False)
     fw32 = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
     got = _run_hip(lstm_hip, N, S, B, P, xi, ti, h0, c0, flags=lstm_hip.BF16_RECURRENCE)
     for t in range(1, S):
-        for name in ("h", "c", "g"):
+        for name in ("h", "c", "g", "probs"):
             assert gu.max_rel(got[name][t - 1], fw[name][t]) <= 2e-3, (name, t)
     assert abs(got["loss"] - fw["loss_bits"]) <= 1e-3 * (S - 1)
     rep = gu.grads_report(got["grads"], dref, N)
@@ -720,11 +722,13 @@ def test_configs4_full_size_window_vs_oracle(bf16):
     P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=4, scale=0.02, empty=((1, 3),))
     orc = Oracle("f32_omp")
     orc.set_bf16_recurrence(bf16)
+    orc.set_bf16_products(bf16)
     try:
         fw = orc.forward(N, 256, S, B, P, xi, ti, h0, c0)
         dref = orc.backward(N, 256, S, B, P, xi, ti, fw)
     finally:
         orc.set_bf16_recurrence(False)
+        orc.set_bf16_products(False)
     got = _run_hip(lstm_hip, N, S, B, P, xi, ti, h0, c0, flags=lstm_hip.BF16_RECURRENCE if bf16 else 0)
     act_tol, loss_tol, grad_tol = (2e-3, 1e-3, 1e-2) if bf16 else (ACT_TOL, LOSS_TOL, GRAD_TOL)
     for t in (1, 2, S // 2, S - 2, S - 1):
@@ -739,19 +743,23 @@ def test_bf16_flag_is_refused_where_unsupported(oracle32):
     import lstm_hip
     with pytest.raises(lstm_hip.LstmHipError):
         lstm_hip.Lstm(64, 5, 8, flags=lstm_hip.BF16_RECURRENCE)   # N not a multiple of 128
-    # the bf16 backward recurrence runs 8-column groups, N/16 * ceil(B/8) workgroups that must be co-resident (one per CU
-    # in the fused form): 16 * 17 = 272 > 256 CUs is refused at create, before any allocation ...
+    # the persistent grids must be co-resident: hidden 1024 with 128 streams needs 1024 forward workgroups of 512 threads
+    # (four to a CU) -- refused at create, before any allocation, with the reason ...
     with pytest.raises(lstm_hip.LstmHipError, match="co-resident"):
-        lstm_hip.Lstm(256, 5, 136, flags=lstm_hip.BF16_RECURRENCE)
-    # ... and the largest grid that fits (16 * 16 = 256) runs and matches the bf16 oracle
-    N, S, B = 256, 5, 128
+        lstm_hip.Lstm(1024, 5, 128, flags=lstm_hip.BF16_RECURRENCE)
+    with pytest.raises(lstm_hip.LstmHipError, match="multiple of 8"):
+        lstm_hip.Lstm(256, 5, 20, flags=lstm_hip.BF16_RECURRENCE)  # bf16 operand rows must stay 16-byte aligned
+    # ... while a batch whose 8-column groups do not fit (16 * 17 = 272 > 256 CUs) runs on 16-column groups (16 * 9)
+    N, S, B = 256, 5, 136
     P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=5, scale=0.05)
     oracle32.set_bf16_recurrence(True)
+    oracle32.set_bf16_products(True)
     try:
         fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
         dref = oracle32.backward(N, 256, S, B, P, xi, ti, fw)
     finally:
         oracle32.set_bf16_recurrence(False)
+        oracle32.set_bf16_products(False)
     got = _run_hip(lstm_hip, N, S, B, P, xi, ti, h0, c0, flags=lstm_hip.BF16_RECURRENCE)
     assert gu.max_rel(got["h"][-1], fw["h"][S - 1]) <= 2e-3
     rep = gu.grads_report(got["grads"], dref, N)
