@@ -502,9 +502,10 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent4(const float4 *
                 bool ok = false;
                 for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
                     bool good = true;
+                    FSTAMP(3, 13) // issue time of the latest poll: at exit, of the one that succeeded
 #pragma unroll
                     for (int i = 0; i < NL; i++) {
-                        b[i] = ld_sc1(rHx, off + 128 * i);
+                        b[i] = ld_sc1(rHx, off + 128 * i); // (nt and sc0|sc1 loads measured the same: 265-266 us)
                         good = good && hx_ready(b[i]);
                     }
                     if (STAMP) polls = spins + 1;

@@ -49,6 +49,8 @@ for wg in range(2):
         ("gating wave 8: publish + reset + off-chain stores issued", s[t, 4] - s[t, 3]),
         ("barrier released -> h_t published (gating wave, on the chain)", s[t, 3] - s[t, 1]),
         ("h_t published -> next barrier released (product waves, on the chain)", s[t + 1, 1] - s[t, 3]),
+        ("   h_t published (this workgroup) -> issue of wave 3's successful poll", s[t + 1, 13] - s[t, 3]),
+        ("   issue -> return of that poll (load round trip)", s[t + 1, 9] - s[t + 1, 13]),
     ])
 
 df = os.environ.get("LSTM_HIP_BWD_HANDOFF", "c")[0] == "f"
