@@ -24,9 +24,10 @@ struct ParamLayout {
 // ---- recurrent weight repack (once per window, after Adagrad) -------------------------------
 // Ufwd[N/4][N/16][64] float4 : MFMA 16x16x4 A-fragments of U for the forward product
 // Ubwd[N/16][N/4][64] float4 : A-fragments of U^T for the backward product
-// Ubwd4 / Ufwd4 (optional): the 4x4x1 images of the 8-column backward / forward forms
+// Ubwd4 / Ufwd4 (optional): the 4x4x1 images of the 8-column backward / forward forms; half_forms: Ufwd4 receives the
+// image of the two-half forward form (k_fwd_persistent6) instead
 void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, float4 *Ubwd4 = nullptr,
-            float4 *Ufwd4 = nullptr);
+            float4 *Ufwd4 = nullptr, int half_forms = 0);
 bool fwd_uses_8col_form(int N, int B, int n_cus); // forward recurrence on 8-column groups (k_fwd_persistent4, Ufwd4 image)
 bool bwd_uses_m4(int N, int cols, bool bf16);     // backward recurrence on v_mfma_f32_4x4x1 (8-column groups, fp32, Ubwd4 image)
 
@@ -59,6 +60,18 @@ int fwd_ring_advance(int ring_base, int S);
 void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
                      int poll_cfg, hipStream_t st, unsigned long long *stamps = nullptr);
+// two-half form (N = 512): the same grid and ring, each workgroup's eight columns advanced as two alternating 4-column
+// recurrences; weights in the Ufwd5 image (pack_U / adagrad with half_forms)
+bool fwd_uses_two_half_form(int N, int B, int n_cus);
+void fwd_persistent6(const float4 *Ufwd5, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
+                     float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
+                     int poll_cfg, hipStream_t st, unsigned long long *stamps = nullptr);
+// two-half form of the backward recurrence (N = 512, 8-column groups, unfused): Ubwd5 image (pack_U / adagrad with bit 1 of
+// half_forms), dg ring DGx as for the data-as-flag hand-off
+bool bwd_halves_supported(int N, int B, int n_cus);
+void bwd_halves(const float4 *Ubwd5, float *DG, const float *DHy, const float *G, const float *C, float *DGx, unsigned *cnt,
+                unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int cfg, hipStream_t st,
+                unsigned long long *stamps = nullptr);
 // gpart != null (8-column groups only): fused mode.  The recurrence then also produces DHy on the fly from
 // Why and dY (DHy is not read), and leaves per-column-group partial blocks [dW | - | db | dWhy]
 // (bwd_partial_floats(N) floats each) to be folded in group order; H and xi are read as well.
@@ -133,7 +146,8 @@ void dW_sums(const float *DG, int T, int G4, float *dW, float *db, void *scratch
 // sums are also stored to dP.  by_off: float offset of dby in the flat block (dby is final in dP).
 void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
              hipStream_t st, float4 *Ubwd4 = nullptr, float4 *Ufwd4 = nullptr, const float *gpart = nullptr, int n_groups = 0,
-             size_t group_stride = 0, size_t by_off = 0, const float *slabs = nullptr, int n_slabs = 0, size_t slab_stride = 0);
+             size_t group_stride = 0, size_t by_off = 0, const float *slabs = nullptr, int n_slabs = 0, size_t slab_stride = 0,
+             int half_forms = 0);
 
 // ---- window builder on the device (OV/lstm_eigen_opt/lstm.cc:190-213): x/target rings + flat copies,
 //      cursor advance, and the h/c carry (column 1 -> column 0).  Single workgroup.

@@ -62,9 +62,32 @@ __device__ __forceinline__ size_t ufwd4_index(int row, int k, int N) { // float 
     const int l = 32 * xp + 4 * (u & 7) + gate;
     return (((((((size_t)(u >> 4) * 8 + w) * 2 + ((u >> 3) & 1)) * (Kw / 32) + L) * 2 + eh) * 2 + (s >> 2)) * 64 + l) * 4 + (s & 3);
 }
+//   Ufwd5[kb][w][ab][l].r (the 4-column-half form of the forward recurrence, k_fwd_persistent6; stored through the Ufwd4
+//        pointer when `half_forms` is set): wave w of workgroup kb owns input indices [Kw*w, Kw*(w+1)), Kw = N/8; lane
+//        l = 4*unit + gate;  = U[gate of unit 16*kb + unit][Kw*w + 4*ab + r]
+__device__ __forceinline__ size_t ufwd5_index(int row, int k, int N) { // float index of U[row][k] in Ufwd5
+    const int gate = row / N, u = row % N, Kw = N / 8, w = k / Kw, kk = k % Kw;
+    const int l = 4 * (u & 15) + gate;
+    return ((((size_t)(u >> 4) * 8 + w) * (Kw / 4) + (kk >> 2)) * 64 + l) * 4 + (kk & 3);
+}
+//   Ubwd5[kb][w][m][r][l].z' (the 4-column-half form of the backward recurrence, k_bwd_halves; stored through the Ubwd4
+//        pointer when bit 1 of `half_forms` is set): wave w of workgroup kb owns gate rows [Kw*w, Kw*(w+1)), Kw = N/2;
+//        lane l = 16Y + 4z + j;  = U[Kw*w + 64m + 16Y + 4z' + r][16*kb + 4z + j]
+__device__ __forceinline__ size_t ubwd5_index(int gk, int hr, int N) { // float index of U[gk][hr] in Ubwd5
+    const int Kw = N / 2, w = gk / Kw, kk = gk % Kw, m = kk >> 6, rem = kk & 63;
+    const int Y = rem >> 4, zp = (rem >> 2) & 3, r = rem & 3, l = 16 * Y + (hr & 15);
+    return ((((((size_t)(hr >> 4) * 8 + w) * (Kw / 64) + m) * 4 + r) * 64 + l) * 4) + zp;
+}
+// half_forms: bit 0 = the forward image is Ufwd5, bit 1 = the backward image is Ubwd5
+__device__ __forceinline__ size_t ufwd45_index(int row, int k, int N, int half_forms) {
+    return (half_forms & 1) ? ufwd5_index(row, k, N) : ufwd4_index(row, k, N);
+}
+__device__ __forceinline__ size_t ubwd45_index(int gk, int hr, int N, int half_forms) {
+    return (half_forms & 2) ? ubwd5_index(gk, hr, N) : ubwd4_index(gk, hr, N);
+}
 __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, float4 *__restrict__ Ufwd,
                                                 float4 *__restrict__ Ubwd, float4 *__restrict__ Ubwd4,
-                                                float4 *__restrict__ Ufwd4, int N) {
+                                                float4 *__restrict__ Ufwd4, int N, int half_forms) {
     const int G4 = 4 * N;
     const size_t nf4 = (size_t)N * N; // float4 count of each image (4N*N floats)
     const size_t total = ((Ubwd4 || Ufwd4) ? 3 : 2) * nf4;
@@ -75,17 +98,17 @@ __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, flo
             const float4 p = *reinterpret_cast<const float4 *>(U + (size_t)k * G4 + r);
             float *u4 = reinterpret_cast<float *>(Ubwd4);
             if (Ubwd4 != nullptr) {
-                u4[ubwd4_index(r + 0, k, N)] = p.x;
-                u4[ubwd4_index(r + 1, k, N)] = p.y;
-                u4[ubwd4_index(r + 2, k, N)] = p.z;
-                u4[ubwd4_index(r + 3, k, N)] = p.w;
+                u4[ubwd45_index(r + 0, k, N, half_forms)] = p.x;
+                u4[ubwd45_index(r + 1, k, N, half_forms)] = p.y;
+                u4[ubwd45_index(r + 2, k, N, half_forms)] = p.z;
+                u4[ubwd45_index(r + 3, k, N, half_forms)] = p.w;
             }
             if (Ufwd4 != nullptr) {
                 float *f4 = reinterpret_cast<float *>(Ufwd4);
-                f4[ufwd4_index(r + 0, k, N)] = p.x;
-                f4[ufwd4_index(r + 1, k, N)] = p.y;
-                f4[ufwd4_index(r + 2, k, N)] = p.z;
-                f4[ufwd4_index(r + 3, k, N)] = p.w;
+                f4[ufwd45_index(r + 0, k, N, half_forms)] = p.x;
+                f4[ufwd45_index(r + 1, k, N, half_forms)] = p.y;
+                f4[ufwd45_index(r + 2, k, N, half_forms)] = p.z;
+                f4[ufwd45_index(r + 3, k, N, half_forms)] = p.w;
             }
         } else if (e < nf4) {
             int l = (int)(e & 63);
@@ -110,11 +133,11 @@ __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, flo
         }
     }
 }
-void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, float4 *Ubwd4, float4 *Ufwd4) {
+void pack_U(const float *U, float4 *Ufwd, float4 *Ubwd, int N, hipStream_t st, float4 *Ubwd4, float4 *Ufwd4, int half_forms) {
     size_t n = ((Ubwd4 || Ufwd4) ? 3 : 2) * (size_t)N * N;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_pack_U, dim3(blocks), dim3(256), 0, st, U, Ufwd, Ubwd, Ubwd4, Ufwd4, N);
+    hipLaunchKernelGGL(k_pack_U, dim3(blocks), dim3(256), 0, st, U, Ufwd, Ubwd, Ubwd4, Ufwd4, N, half_forms);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1203,7 +1226,8 @@ template <bool FOLD>
 __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *__restrict__ dP,
                                                  float *__restrict__ mem, size_t n4, float lr, size_t u_off4, int N,
                                                  float4 *__restrict__ Ufwd, float4 *__restrict__ Ubwd,
-                                                 float4 *__restrict__ Ubwd4, float4 *__restrict__ Ufwd4, GradFold fold) {
+                                                 float4 *__restrict__ Ubwd4, float4 *__restrict__ Ufwd4, GradFold fold,
+                                                 int half_forms) {
     const size_t u_n4 = (size_t)N * N; // float4 count of U
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 p = reinterpret_cast<float4 *>(P)[i];
@@ -1243,17 +1267,17 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *_
             if (Ubwd != nullptr) Ubwd[((size_t)(k >> 4) * (N / 4) + (r >> 4)) * 64 + (((r & 15) >> 2) << 4) + (k & 15)] = p;
             if (Ubwd4 != nullptr) {
                 float *u4 = reinterpret_cast<float *>(Ubwd4);
-                u4[ubwd4_index(r + 0, k, N)] = p.x;
-                u4[ubwd4_index(r + 1, k, N)] = p.y;
-                u4[ubwd4_index(r + 2, k, N)] = p.z;
-                u4[ubwd4_index(r + 3, k, N)] = p.w;
+                u4[ubwd45_index(r + 0, k, N, half_forms)] = p.x;
+                u4[ubwd45_index(r + 1, k, N, half_forms)] = p.y;
+                u4[ubwd45_index(r + 2, k, N, half_forms)] = p.z;
+                u4[ubwd45_index(r + 3, k, N, half_forms)] = p.w;
             }
             if (Ufwd4 != nullptr) {
                 float *f4 = reinterpret_cast<float *>(Ufwd4);
-                f4[ufwd4_index(r + 0, k, N)] = p.x;
-                f4[ufwd4_index(r + 1, k, N)] = p.y;
-                f4[ufwd4_index(r + 2, k, N)] = p.z;
-                f4[ufwd4_index(r + 3, k, N)] = p.w;
+                f4[ufwd45_index(r + 0, k, N, half_forms)] = p.x;
+                f4[ufwd45_index(r + 1, k, N, half_forms)] = p.y;
+                f4[ufwd45_index(r + 2, k, N, half_forms)] = p.z;
+                f4[ufwd45_index(r + 3, k, N, half_forms)] = p.w;
             }
             if (Ufwd == nullptr) continue;
             // Ufwd[jb][k4][l].i = U[(l&3)*N + 4*jb + ((l&15)>>2)][16*k4 + 4*(l>>4) + i]
@@ -1272,17 +1296,17 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *_
 }
 void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
              hipStream_t st, float4 *Ubwd4, float4 *Ufwd4, const float *gpart, int n_groups, size_t group_stride, size_t by_off,
-             const float *slabs, int n_slabs, size_t slab_stride) {
+             const float *slabs, int n_slabs, size_t slab_stride, int half_forms) {
     const size_t n4 = n / 4; // the flat block is a multiple of 4 floats (M = 256, N % 16 == 0)
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     const GradFold fold{gpart, n_groups, group_stride, by_off / 4, slabs, n_slabs, slab_stride};
     if (gpart != nullptr)
         hipLaunchKernelGGL(k_adagrad<true>, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4,
-                           Ufwd4, fold);
+                           Ufwd4, fold, half_forms);
     else
         hipLaunchKernelGGL(k_adagrad<false>, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4,
-                           Ufwd4, fold);
+                           Ufwd4, fold, half_forms);
 }
 
 // ------------------------------------------------------------------------------------------------

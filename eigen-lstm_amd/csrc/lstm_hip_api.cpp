@@ -110,7 +110,9 @@ struct lstm_hip_ctx {
     float *P = nullptr, *dP = nullptr, *mem = nullptr;
     float4 *Ufwd = nullptr, *Ubwd = nullptr;
     float4 *Ubwd4 = nullptr; // weight image of the 4x4x1 backward form (kernels.hip, k_pack_U), when bwd_uses_m4
-    float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel, when fwd_uses_8col_form
+    float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel (fwd_uses_8col_form) or, fwd_cols4, of the two-half one
+    int bwd_halves = 0;      // 1: backward recurrence likewise (k_bwd_halves; LSTM_HIP_BWD_HALVES=1, unfused gradient sums)
+    int fwd_cols4 = 0;       // 1: forward recurrence as two alternating 4-column halves per workgroup (k_fwd_persistent6)
     float *Hx = nullptr;     // 8-column forward form: ring of hand-off slots (data-as-flag), sentinel-filled
     int ring_base = 0;       // slot of step 0 in the next launch
     float *DGx = nullptr;    // backward recurrence: the same kind of ring for dg
@@ -242,6 +244,10 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
         }
         RUN(K_FWD_PERSIST, fwd_persistent_bf16(h->Ufwd16, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi,
                                                h->cnt, h->abortp, h->fwd_epoch, N, S, B, fast, h->st));
+    } else if (h->Hx && h->fwd_cols4) {
+        RUN(K_FWD_PERSIST, fwd_persistent6(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
+                                           h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st, h->stamps));
+        h->ring_base = fwd_ring_advance(h->ring_base, S);
     } else if (h->Hx) {
         RUN(K_FWD_PERSIST, fwd_persistent4(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
                                            h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st, h->stamps));
@@ -258,7 +264,7 @@ int do_forward(lstm_hip_ctx *h) {
     const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
     if (!h->packed && !h->bf16) { // (the bf16 path packs its own images, launch_fwd_recurrence)
         RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd4 ? nullptr : h->Ufwd, h->Ubwd4 ? nullptr : h->Ubwd, N, h->st, h->Ubwd4,
-                             h->Ufwd4)); // one image per direction is live
+                             h->Ufwd4, h->fwd_cols4 | (h->bwd_halves ? 2 : 0))); // one image per direction is live
         h->packed = true;
     }
     h->n_dby_parts = softmax_parts(h->T);
@@ -318,6 +324,10 @@ int do_backward(lstm_hip_ctx *h) {
             RUN(K_BWD_PERSIST, bwd_persistent(reinterpret_cast<const float4 *>(h->Ubwd16), h->DG, h->DHy, h->G, h->C, h->H,
                                               h->xi, fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp,
                                               h->bwd_epoch, N, S, B, h->bwd_cols, h->st, nullptr, h->DGb));
+        } else if (h->bwd_halves) {
+            RUN(K_BWD_PERSIST, bwd_halves(h->Ubwd4, h->DG, h->DHy, h->G, h->C, h->DGx, cb, h->abortp, h->bwd_epoch, h->ring_base_b, N,
+                                          S, B, h->bwd_halves >> 1, h->st, h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr));
+            h->ring_base_b = bwd_ring_advance(h->ring_base_b, S);
         } else {
             RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd4 ? h->Ubwd4 : h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi,
                                               fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp, h->bwd_epoch, N, S,
@@ -422,12 +432,12 @@ int do_adagrad(lstm_hip_ctx *h, double lr) {
         RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
                                h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, h->gpart, NGb, bwd_partial_floats(h->cfg.N),
                                h->pl.by, h->n_slabs_dU > 0 ? h->slabs_dU : nullptr, h->n_slabs_dU,
-                               (size_t)4 * h->cfg.N * h->cfg.N));
+                               (size_t)4 * h->cfg.N * h->cfg.N, h->fwd_cols4 | (h->bwd_halves ? 2 : 0)));
     } else if (h->bf16) // the fp32 fragment images are not used by the bf16 path (its own are repacked by pack_U_bf16)
         RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, nullptr, nullptr, h->st));
     else
     RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
-                           h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4));
+                           h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, nullptr, 0, 0, 0, nullptr, 0, 0, h->fwd_cols4 | (h->bwd_halves ? 2 : 0)));
     h->packed = true; // the fp32 U images were refreshed by the same launch (the bf16 path has none)
     h->packed16 = false;
     h->why_packed = false;
@@ -567,16 +577,21 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
         ALLOC(h->Ubwd4, N * N);
         // hand-off of the backward recurrence: sharded counters (default) or the data-as-flag ring ("flag"); read per handle
         const char *e = getenv("LSTM_HIP_BWD_HANDOFF");
-        if (e && e[0] == 'f') {
+        const char *bh = getenv("LSTM_HIP_BWD_HALVES");
+        h->bwd_halves = !(bh && atoi(bh) != 0 && !want_fused) ? 0 : (atoi(bh) | 1) * (int) bwd_halves_supported((int)N, (int)B, prop.multiProcessorCount);
+        if ((e && e[0] == 'f') || h->bwd_halves) {
             ALLOC(h->DGx, bwd_ring_floats((int)N, (int)B));
             HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * bwd_ring_floats((int)N, (int)B)));
         }
     }
     if (h->persistent && !h->bf16 && fwd_uses_8col_form((int)N, (int)B, prop.multiProcessorCount)) {
+        const char *pp = getenv("LSTM_HIP_FWD_HALVES"); // "0": one 8-column recurrence per workgroup (A/B; per handle)
+        h->fwd_cols4 = fwd_uses_two_half_form((int)N, (int)B, prop.multiProcessorCount) && !(pp && atoi(pp) == 0);
         ALLOC(h->Ufwd4, N * N);
         ALLOC(h->Hx, fwd_ring_floats((int)N, (int)B));
         HIP_TRY(hipMemset(h->Hx, 0xff, sizeof(float) * fwd_ring_floats((int)N, (int)B)));
-        h->poll_cfg = getenv("LSTM_HIP_FWD_POLL") ? atoi(getenv("LSTM_HIP_FWD_POLL")) : 1; // tuning knob (flat from 0 to 4)
+        // tuning knob (flat from 0 to 4 for the one-recurrence form; the two-half form polls without pause)
+        h->poll_cfg = getenv("LSTM_HIP_FWD_POLL") ? atoi(getenv("LSTM_HIP_FWD_POLL")) : (h->fwd_cols4 ? 0 : 1);
     }
     if (h->persistent && want_fused && h->bwd_cols == 8)
         ALLOC(h->gpart, (size_t)((B + h->bwd_cols - 1) / h->bwd_cols) * bwd_partial_floats(cfg->N));

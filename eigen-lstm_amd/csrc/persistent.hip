@@ -668,6 +668,245 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent4(const float4 *
 #undef FSTAMP_VAL
 
 // ------------------------------------------------------------------------------------------------
+// forward recurrence, two half-groups per workgroup (N = 512): the grid, ring and gating of k_fwd_persistent4, but the
+// eight columns of a workgroup are TWO independent recurrences of four columns, A and B, which the workgroup advances
+// alternately.  A step of one recurrence is a chain  publish -> L2 -> poll hit -> MFMA -> fold -> gates -> publish  whose
+// latencies (the hand-off alone: 2 700 of 6 300 cycles) the matrix pipe sits out; with two recurrences in one workgroup
+// the product waves run B's MFMAs while A's h_t is being gated, published and fetched, and the other way round.  Each
+// chain's period is then  hand-off + gates + HALF the MFMAs, and both chains complete a step per period.  (Two
+// workgroups per CU on different 4-column groups would be the hardware's version of this; measured slower -- twice the
+// polling waves, and which workgroups share a CU is the dispatcher's choice.)
+//
+// Product: v_mfma_f32_4x4x1, block = unit (lane = 4*unit + j), CBSZ = 4 / ABID = ab: all sixteen unit-blocks read the four
+// columns of h[k] from block ab of the loaded register -- ONE 16-byte load per lane (64 values of k x 4 columns) feeds the
+// wave's 64 instructions of a half-step:
+//   D[i][j] (+)= h[k = Kw*w + 4*ab + r][column i of the half] * U[gate j of unit 16*kb + unit][k]       (r = register)
+// Weights Ufwd5 (k_pack_U, ufwd5_index), one copy for both halves.  Wave 8 gates half A (64 pairs), wave 9 half B.
+// The loop has NO workgroup barrier: the product waves count their partial-sum images into an LDS word per half, the
+// gating wave of the half waits for the count, and the images are double-buffered by step parity (reuse is ordered by the
+// ring itself: a product wave writing step t+2 has fetched h_{t+1}, published after the gating wave read image t+1).
+// The waves of the two halves therefore never wait for each other, only for data.
+// ------------------------------------------------------------------------------------------------
+#define FSTAMP(wave, k)                                                                                        \
+    if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
+        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = __builtin_amdgcn_s_memtime();
+template <bool FAST, bool STAMP = false>
+__global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *__restrict__ Ufwd5, const float *__restrict__ W,
+                                                                  const float *__restrict__ bias, float *H, float *__restrict__ C,
+                                                                  float *__restrict__ G, const int32_t *__restrict__ xi,
+                                                                  float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch,
+                                                                  int ring_base, int S, int B, int poll_cfg,
+                                                                  unsigned long long *stamps = nullptr) {
+    constexpr int N = 512, G4 = 4 * N, Kw = N / 8, RS = 68; // RS: padded row of the partial-sum image (bank spread)
+    static_assert(Kw == 64, "one 16-byte load per lane covers a wave's K-slice of a half");
+    __shared__ __attribute__((aligned(16))) float red[2][2][8 * 4 * RS]; // [half][step parity][wave][column][4*unit + gate]
+    __shared__ int s_abort;
+    __shared__ unsigned s_done[2]; // per half: partial-sum images written so far, summed over the product waves (8 per step)
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int NB3 = gridDim.x, NG = gridDim.y;
+    const int lin_ = blockIdx.x + NB3 * blockIdx.y;
+    const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
+    const __amdgpu_buffer_rsrc_t rH = make_rsrc(H, (size_t)S * N * B * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rHx = make_rsrc(Hx, (size_t)HX_RING * N * B * sizeof(float));
+    unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
+    if (tid == 0) {
+        s_abort = 0;
+        s_done[0] = s_done[1] = 0;
+        if (XCD_LOCAL) {
+            __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // visible before anything this workgroup publishes
+        }
+    }
+    const int poll_sleep = poll_cfg & 255;
+    __syncthreads();
+
+    if (w < 8) {
+        // ---------------- waves 0-7: the product, half A then half B ----------------
+        const int lb = l >> 2, li = l & 3; // lane = 4*block + i
+        float4 wq[16];
+#pragma unroll
+        for (int ab = 0; ab < 16; ab++) wq[ab] = Ufwd5[(((size_t)kb * 8 + w) * 16 + ab) * 64 + l];
+        int colv[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            const int c = 8 * g + 4 * hf + li;
+            colv[hf] = c < B ? c : B - 1;
+        }
+        // h_0 of both halves (plain window state in H); later fragments come from the ring, requested a half-step ahead
+        float4 bvq[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) bvq[hf] = ld_sc1(rH, (int)((((size_t)colv[hf]) * N + Kw * w + 4 * lb) * sizeof(float)));
+        for (int t = 1; t < S; t++) {
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                if (hf == 0) { FSTAMP(3, 8) }
+                float4 bv = bvq[hf];
+                if (t > 1 && !__all(hx_ready(bv))) {
+                    // The fragment requested ahead came back incomplete: fetch the K-slice again until no word of it is the
+                    // sentinel.  No one-request hint ahead of it as in k_fwd_persistent4: here the wave has the other half
+                    // to work on, arrives late at most polls, and the hint's extra round trip costs more than it saves
+                    // (measured 243 us with the hint, 229-232 without).
+                    const int slot = (t - 1 + ring_base) & (HX_RING - 1);
+                    const int off = (int)((((size_t)slot * B + colv[hf]) * N + Kw * w + 4 * lb) * sizeof(float));
+                    bool ok = false;
+                    for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                        bv = ld_sc1(rHx, off);
+                        if (__all(hx_ready(bv))) {
+                            ok = true;
+                            break;
+                        }
+                        if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        for (int i = 0; i < poll_sleep; i++) __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (!ok) {
+                        if (l == 0) {
+                            __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        return;
+                    }
+                }
+                if (hf == 0) { FSTAMP(3, 9) } else { FSTAMP(3, 5) }
+                // the OTHER half's next fragment -- (t, B) after A's product, (t+1, A) after B's -- is requested now and
+                // looked at after this half's barrier: its round trip runs under the matrix instructions below
+                const int nslot = (t - 1 + hf + ring_base) & (HX_RING - 1);
+                const int noff = (int)((((size_t)nslot * B + colv[hf ^ 1]) * N + Kw * w + 4 * lb) * sizeof(float));
+                const bool req = hf == 0 ? t > 1 : t + 1 < S;
+                // four independent accumulation chains, one per register of the loaded fragment
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+#define F6(ab)                                                              \
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv.x, wq[ab].x, c0, 4, ab, 0); \
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv.y, wq[ab].y, c1, 4, ab, 0); \
+    c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv.z, wq[ab].z, c2, 4, ab, 0); \
+    c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv.w, wq[ab].w, c3, 4, ab, 0);
+                F6(0) F6(1) F6(2) F6(3) F6(4) F6(5) F6(6) F6(7) F6(8) F6(9) F6(10) F6(11) F6(12) F6(13) F6(14) F6(15)
+#undef F6
+                __builtin_amdgcn_sched_barrier(0);
+                if (req) bvq[hf ^ 1] = ld_sc1(rHx, noff); // behind the last matrix instruction (ahead of them: 236-240 us)
+                __builtin_amdgcn_sched_barrier(0);
+                if (hf == 0) { FSTAMP(3, 10) } else { FSTAMP(3, 6) }
+                // lane (unit, gate j), register i = column i of the half: one row of the image per (wave, column)
+                // No workgroup barrier anywhere in the loop: the gating wave of the half counts the images in (LDS operations
+                // of a wave execute in order, so the count lands behind the sums), and an image is overwritten two steps
+                // later, by which time this wave has fetched an h that the gating wave published after reading it.
+                float *rp = red[hf][t & 1];
+#pragma unroll
+                for (int r = 0; r < 4; r++) rp[(w * 4 + r) * RS + l] = (c0[r] + c1[r]) + (c2[r] + c3[r]);
+                asm volatile("" ::: "memory");
+                if (l == 0) __hip_atomic_fetch_add(&s_done[hf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (hf == 0) { FSTAMP(3, 11) } else { FSTAMP(3, 7) }
+            }
+        }
+    } else {
+        // ---------------- wave 8: gates of half A; wave 9: gates of half B; lane = column*16 + unit ----------------
+        const int hf = w - 8;
+        __builtin_amdgcn_s_setprio(3); // the gates are on the chain; the other half's product, issuing beside them, is not
+        const int gc = l >> 4, gu = l & 15;
+        const int col = 8 * g + 4 * hf + gc, colc = col < B ? col : B - 1;
+        const int j = 16 * kb + gu;
+        float bs[4], cprev, wx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++) bs[gt] = bias[gt * N + j];
+        cprev = C[(size_t)colc * N + j];
+        int xnext = xi[1 * B + colc]; // input byte of the NEXT step's column, fetched a step ahead of the W gather
+        bool local_pub = false;
+        const float *rp0 = red[hf][0] + gc * RS + 4 * gu;
+        for (int t = 1; t < S; t++) {
+            // W column of this step's input byte (R/lstm.cc:176 with a one-hot x): in flight while the product runs
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) wx[gt] = 0.f;
+            if (xnext >= 0) {
+#pragma unroll
+                for (int gt = 0; gt < 4; gt++) wx[gt] = W[(size_t)xnext * G4 + gt * N + j];
+            }
+            if (t + 1 < S) xnext = xi[(t + 1) * B + colc];
+            FSTAMP(8, 0)
+            {   // all eight partial-sum images of this half and step are in LDS
+                bool in = false;
+                for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                    in = __hip_atomic_load(&s_done[hf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 8u * (unsigned)t;
+                    if (in || __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!in) {
+                    if (l == 0) {
+                        __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    return;
+                }
+                asm volatile("" ::: "memory");
+            }
+            const float *rp = rp0 + (t & 1) * (8 * 4 * RS);
+            FSTAMP(8, 1)
+            if (XCD_LOCAL && t == 2) { // every workgroup of the group has published h_1, hence its XCC id before it
+                unsigned mine = 0;
+                bool same = true;
+                if (l < NB3) {
+                    mine = __hip_atomic_load(xcc_tab + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    same = (mine >> 4) == epoch;
+                }
+                const unsigned first = __builtin_amdgcn_readfirstlane(mine);
+                if (l < NB3) same = same && mine == first;
+                local_pub = (XCD_FORCE_LOCAL || __all(same)) && NB3 <= 64;
+            }
+            // the four gates of (unit gu, column gc) sit side by side in every wave's row gc: one 16-byte read each
+            float4 uh = *reinterpret_cast<const float4 *>(rp);
+#pragma unroll
+            for (int ww = 1; ww < 8; ww++) {
+                const float4 v = *reinterpret_cast<const float4 *>(rp + ww * 4 * RS);
+                uh.x += v.x;
+                uh.y += v.y;
+                uh.z += v.z;
+                uh.w += v.w;
+            }
+            const float pre0 = (wx[0] + uh.x) + bs[0], pre1 = (wx[1] + uh.y) + bs[1]; // R/lstm.cc:176
+            const float pre2 = (wx[2] + uh.z) + bs[2], pre3 = (wx[3] + uh.w) + bs[3];
+            const float ig = p_sigm<FAST>(pre0), og = p_sigm<FAST>(pre1), fg = p_sigm<FAST>(pre2); // :179
+            const float ug_ = p_tanh<FAST>(pre3);                                                 // :182
+            const float cv = p_tanh<FAST>(ig * ug_ + fg * cprev);                                 // :185-189
+            const float hv = og * cv;                                                             // :192
+            cprev = cv;
+            float4 h4;
+            h4.x = dpp_f<0x00>(hv);
+            h4.y = dpp_f<0x55>(hv);
+            h4.z = dpp_f<0xAA>(hv);
+            h4.w = dpp_f<0xFF>(hv);
+            FSTAMP(8, 2)
+            // the reset this wave issued a step ago (and every older store) has completed before h_t can be seen
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FSTAMP(8, 3)
+            if ((gu & 3) == 0 && col < B) {
+                const float4 hp = {hx_canon(h4.x), hx_canon(h4.y), hx_canon(h4.z), hx_canon(h4.w)};
+                const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
+                                     __uint_as_float(HX_SENT)};
+                const size_t e_pub = ((size_t)((t + ring_base) & (HX_RING - 1)) * B + col) * N + j;
+                const size_t e_rst = ((size_t)((t + 2 + ring_base) & (HX_RING - 1)) * B + col) * N + j;
+                if (XCD_LOCAL && local_pub) {
+                    *reinterpret_cast<float4 *>(Hx + e_pub) = hp;
+                    *reinterpret_cast<float4 *>(Hx + e_rst) = sent;
+                } else {
+                    st_sc1(hp, rHx, (int)(e_pub * sizeof(float)));
+                    st_sc1(sent, rHx, (int)(e_rst * sizeof(float)));
+                }
+                *reinterpret_cast<float4 *>(H + ((size_t)t * B + col) * N + j) = h4;
+            }
+            if (col < B) {
+                float *gcp = G + ((size_t)t * B + col) * G4 + j;
+                gcp[0] = ig;
+                gcp[N] = og;
+                gcp[2 * N] = fg;
+                gcp[3 * N] = ug_;
+                C[((size_t)t * B + col) * N + j] = cv;
+            }
+            FSTAMP(8, 4)
+        }
+    }
+}
+#undef FSTAMP
+
+// ------------------------------------------------------------------------------------------------
 // bf16 recurrence (LSTM_HIP_BF16_RECURRENCE, BASELINE configs[4]): the operands of U*h_prev are bfloat16
 // (round-to-nearest-even of the fp32 master weights and of the published h), the accumulation is fp32,
 // everything else is the fp32 kernel above.  MFMA 16x16x32 bf16: A[row=l&15][k=8*(l>>4)+j],
@@ -961,6 +1200,273 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// backward recurrence, two half-groups per workgroup (N = 512, 8-column groups; the backward twin of k_fwd_persistent6).
+// grid (N/16, ceil(B/8)), 640 threads.  The eight columns of workgroup (kb, g) are two independent recurrences of four
+// columns, A and B: while A's dg_t is computed elementwise, published and fetched by the group, the eight product waves
+// run B's  dhnext = U^T dg_{t+1}  and the other way round.
+//   waves 0-7  product; K = 4N split over the waves (Kw = N/2 gate rows each), v_mfma_f32_4x4x1 with block = 4Y + z:
+//                D[i][j] += dg[k = Kw*w + 64m + 16Y + 4z' + r][column 4*half + i] * U^T[unit 4z + j][k]
+//              CBSZ = 2 / ABID = z': the four z-blocks of a Y-group read their dg from block z' of the loaded register,
+//              so a lane's 16-byte load m (lane = 16Y + 4z' + i: 16 consecutive bytes of k, 256 per column) feeds
+//              sixteen instructions; weights Ubwd5 (ubwd5_index), 64 registers; 64 instructions per half and step.
+//   wave 8 / 9 elementwise (R/lstm.cc:228-247,256) of half A / B: lane = column*16 + unit, folds the 8 x 4 (wave, Y)
+//              partial sums, publishes dg_t to the ring DGx (data-as-flag, as in k_bwd_persistent<.., DF>) and stores
+//              the plain DG the dU / dW products read after the launch.
+// No workgroup barrier in the loop (LDS count per half, partial sums double-buffered by step parity).
+// ------------------------------------------------------------------------------------------------
+constexpr int BWDH_THREADS = 640;
+#define HSTAMP(wave, k)                                                                                        \
+    if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
+        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = __builtin_amdgcn_s_memtime();
+template <bool STAMP = false>
+__global__ __launch_bounds__(BWDH_THREADS) void k_bwd_halves(const float4 *__restrict__ Ubwd5, float *DG,
+                                                             const float *__restrict__ DHy, const float *__restrict__ G,
+                                                             const float *__restrict__ C, float *DGx, unsigned *cnt,
+                                                             unsigned *abortp, unsigned epoch, int ring_base, int S, int B,
+                                                             int cfg, unsigned long long *stamps = nullptr) {
+    constexpr int N = 512, G4 = 4 * N, Kw = N / 2, NL = Kw / 64; // NL 16-byte loads per lane, half and step
+    constexpr int WS = 256;                                      // partial-sum image: [wave][column*16 + unit][Y]
+    __shared__ __attribute__((aligned(16))) float red[2][2][8 * WS]; // [half][step parity]
+    __shared__ int s_abort;
+    __shared__ unsigned s_done[2];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int NBK = gridDim.x, NG = gridDim.y;
+    const int lin_ = blockIdx.x + NBK * blockIdx.y;
+    const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
+    const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DGx, (size_t)HX_RING * G4 * B * sizeof(float));
+    unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
+    if (tid == 0) {
+        s_abort = 0;
+        s_done[0] = s_done[1] = 0;
+        if (XCD_LOCAL) {
+            __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // visible before anything this workgroup publishes
+        }
+    }
+    __syncthreads();
+
+    if (w < 8) {
+        // ---------------- product waves ----------------
+        const int lY = l >> 4, lz = (l >> 2) & 3, li = l & 3;
+        float4 a[4 * NL];
+#pragma unroll
+        for (int i = 0; i < 4 * NL; i++) a[i] = Ubwd5[(((size_t)kb * 8 + w) * (4 * NL) + i) * 64 + l];
+        int cofs[2]; // float offset of this lane's first fragment inside a step slot
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            const int c = 8 * g + 4 * hf + li, cc_ = c < B ? c : B - 1;
+            cofs[hf] = cc_ * G4 + Kw * w + 16 * lY + 4 * lz;
+        }
+        // hint: lane i < Kw/16 looks at producer workgroup i of this wave's K-slice (one gate, Kw consecutive units): the
+        // 16 bytes its elementwise wave stores from its last lane (column 3 of the half, units 12-15)
+        const bool use_hint = (cfg & 1) != 0, spec_a = (cfg & 2) == 0;
+        int hint_ofs[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            const int c = 8 * g + 4 * hf + 3, cc_ = c < B ? c : B - 1;
+            hint_ofs[hf] = cc_ * G4 + Kw * w + 16 * (l & (Kw / 16 - 1)) + 12;
+        }
+        float4 bq[2][NL];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int m = 0; m < NL; m++) bq[hf][m] = float4{0.f, 0.f, 0.f, 0.f};
+        // step t consumes dg_{t+1} from slot(t+1); the first product step is t = S-2.  Requests run one half-step ahead.
+        auto slot_off = [&](int tt, int hf) { return (int)(((size_t)((tt + ring_base) & (HX_RING - 1)) * B * G4 + cofs[hf]) * sizeof(float)); };
+        for (int t = S - 2; t >= 1; t--) {
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                if (hf == 0) { HSTAMP(3, 8) }
+                bool good = (t < S - 2 && spec_a) || hf == 1; // (S-2, A) has not been requested yet
+                if (good)
+#pragma unroll
+                    for (int m = 0; m < NL; m++) good = good && hx_ready(bq[hf][m]);
+                if (!__all(good)) {
+                    const int off = slot_off(t + 1, hf);
+                    if (use_hint) { // one request per wave until the last-stored piece of each producer of this K-slice is in
+                        const int hoff = (int)(((size_t)((t + 1 + ring_base) & (HX_RING - 1)) * B * G4 + hint_ofs[hf]) * sizeof(float));
+                        for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                            float4 hv = {0.f, 0.f, 0.f, 0.f};
+                            if (l < Kw / 16) hv = ld_sc1(rDG, hoff);
+                            if (__all(hx_ready(hv))) break;
+                            if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    bool ok = false;
+                    for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                        bool gd = true;
+#pragma unroll
+                        for (int m = 0; m < NL; m++) bq[hf][m] = ld_sc1(rDG, off + 256 * m);
+#pragma unroll
+                        for (int m = 0; m < NL; m++) gd = gd && hx_ready(bq[hf][m]);
+                        if (__all(gd)) {
+                            ok = true;
+                            break;
+                        }
+                        if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    }
+                    if (!ok) {
+                        if (l == 0) {
+                            __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        return;
+                    }
+                }
+                if (hf == 0) { HSTAMP(3, 9) } else { HSTAMP(3, 5) }
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+#define H_STEP(av, wq)                                              \
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.x, c0, 2, 0, 0); \
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.y, c1, 2, 1, 0); \
+    c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.z, c2, 2, 2, 0); \
+    c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.w, c3, 2, 3, 0);
+#pragma unroll
+                for (int m = 0; m < NL; m++) {
+                    H_STEP(bq[hf][m].x, a[4 * m + 0])
+                    H_STEP(bq[hf][m].y, a[4 * m + 1])
+                    H_STEP(bq[hf][m].z, a[4 * m + 2])
+                    H_STEP(bq[hf][m].w, a[4 * m + 3])
+                }
+#undef H_STEP
+                __builtin_amdgcn_sched_barrier(0);
+                // the other half's next fragments: (t, B) behind A's product, (t-1, A) behind B's
+                {
+                    const int tn = hf == 0 ? t : t - 1;
+                    if (tn >= 1 && (hf == 0 || spec_a)) {
+                        const int noff = slot_off(tn + 1, hf ^ 1);
+#pragma unroll
+                        for (int m = 0; m < NL; m++) bq[hf ^ 1][m] = ld_sc1(rDG, noff + 256 * m);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (hf == 0) { HSTAMP(3, 10) } else { HSTAMP(3, 6) }
+                float *rp = red[hf][t & 1] + w * WS + 4 * (4 * lz + li) + lY; // lane (Y, z, j = li): unit 4z + j
+#pragma unroll
+                for (int r = 0; r < 4; r++) rp[64 * r] = (c0[r] + c1[r]) + (c2[r] + c3[r]); // register r = column r of the half
+                asm volatile("" ::: "memory");
+                if (l == 0) __hip_atomic_fetch_add(&s_done[hf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (hf == 0) { HSTAMP(3, 11) } else { HSTAMP(3, 7) }
+            }
+        }
+    } else {
+        // ---------------- elementwise waves: wave 8 half A, wave 9 half B; lane = column*16 + unit ----------------
+        const int hf = w - 8;
+        __builtin_amdgcn_s_setprio(3);
+        const int cc = l >> 4, jj = l & 15;
+        const int ecol = 8 * g + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
+        const int j = 16 * kb + jj;
+        float dcn = 0.0f; // dcnext, R/lstm.cc:217
+        bool local_pub = false;
+        const float *rp0 = red[hf][0] + 4 * (cc * 16 + jj);
+        for (int t = S - 1; t >= 1; t--) {
+            // operands that do not depend on the chain
+            const float *gc = G + ((size_t)t * B + ecolc) * G4 + j;
+            const float ig = gc[0], og = gc[N], fg = gc[2 * N], ug = gc[3 * N];
+            const float cv = C[((size_t)t * B + ecolc) * N + j], cp = C[((size_t)(t - 1) * B + ecolc) * N + j];
+            const float dhy = DHy[((size_t)t * B + ecolc) * N + j];
+            HSTAMP(8, 0)
+            float dhn = 0.0f;
+            if (t < S - 1) {
+                const unsigned want = 8u * (unsigned)(S - 1 - t);
+                bool in = false;
+                for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                    in = __hip_atomic_load(&s_done[hf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want;
+                    if (in || __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!in) {
+                    if (l == 0) {
+                        __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    return;
+                }
+                asm volatile("" ::: "memory");
+                HSTAMP(8, 1)
+                const float *rp = rp0 + (t & 1) * (8 * WS);
+                float4 sm = *reinterpret_cast<const float4 *>(rp); // the four k-classes Y of a wave side by side
+#pragma unroll
+                for (int ww = 1; ww < 8; ww++) {
+                    const float4 v = *reinterpret_cast<const float4 *>(rp + ww * WS);
+                    sm.x += v.x;
+                    sm.y += v.y;
+                    sm.z += v.z;
+                    sm.w += v.w;
+                }
+                dhn = (sm.x + sm.y) + (sm.z + sm.w);
+            }
+            if (XCD_LOCAL && t == S - 2) { // every workgroup of the group has published dg_{S-1}, its XCC id before it
+                unsigned mine = 0;
+                bool same = true;
+                if (l < NBK) {
+                    mine = __hip_atomic_load(xcc_tab + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    same = (mine >> 4) == epoch;
+                }
+                const unsigned first = __builtin_amdgcn_readfirstlane(mine);
+                if (l < NBK) same = same && mine == first;
+                local_pub = (XCD_FORCE_LOCAL || __all(same)) && NBK <= 64;
+            }
+            const float dh = dhy + dhn;                         // R/lstm.cc:228
+            float dcv = dh * og + dcn;                          // :233
+            dcv = dcv * (1.0f - cv * cv);                       // :235
+            const float d_o = (dh * cv) * (og * (1.0f - og));   // :238,244
+            const float d_i = (dcv * ug) * (ig * (1.0f - ig));  // :239,244
+            const float d_f = (dcv * cp) * (fg * (1.0f - fg));  // :240,244
+            const float d_u = (dcv * ig) * (1.0f - ug * ug);    // :241,247
+            dcn = dcv * fg;                                     // :256
+            // 4x4 transpose over the four lanes of a quad by DPP: lane (column cc, unit jj = 4*tq + ta) ends up with gate ta
+            // of units 4*tq .. 4*tq+3, one 16-byte store
+            const int ta = jj & 3, tq = jj >> 2;
+            float t0 = d_i, t1 = d_o, t2 = d_f, t3 = d_u;
+            {
+                const float lo = (ta & 1) ? t0 : t1, hi = (ta & 1) ? t2 : t3;
+                const float rlo = dpp_f<0xB1>(lo), rhi = dpp_f<0xB1>(hi); // quad_perm [1,0,3,2]
+                if (ta & 1) {
+                    t0 = rlo;
+                    t2 = rhi;
+                } else {
+                    t1 = rlo;
+                    t3 = rhi;
+                }
+                const float s0 = (ta & 2) ? t0 : t2, s1 = (ta & 2) ? t1 : t3;
+                const float r0 = dpp_f<0x4E>(s0), r1 = dpp_f<0x4E>(s1); // quad_perm [2,3,0,1]
+                if (ta & 2) {
+                    t0 = r0;
+                    t1 = r1;
+                } else {
+                    t2 = r0;
+                    t3 = r1;
+                }
+            }
+            HSTAMP(8, 2)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's older stores (the last reset) are complete
+            HSTAMP(8, 3)
+            if (ecol < B) {
+                const float4 v = {t0, t1, t2, t3};
+                const float4 vp = {hx_canon(v.x), hx_canon(v.y), hx_canon(v.z), hx_canon(v.w)};
+                const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
+                                     __uint_as_float(HX_SENT)};
+                const size_t within = (size_t)ecol * G4 + ta * N + 16 * kb + 4 * tq;
+                const size_t e_pub = (size_t)((t + ring_base) & (HX_RING - 1)) * B * G4 + within;
+                const size_t e_rst = (size_t)((t - 2 + ring_base) & (HX_RING - 1)) * B * G4 + within;
+                if (XCD_LOCAL && local_pub) {
+                    *reinterpret_cast<float4 *>(DGx + e_pub) = vp;
+                    *reinterpret_cast<float4 *>(DGx + e_rst) = sent;
+                } else {
+                    st_sc1(vp, rDG, (int)(e_pub * sizeof(float)));
+                    st_sc1(sent, rDG, (int)(e_rst * sizeof(float)));
+                }
+                *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
+            }
+            HSTAMP(8, 4)
+        }
+    }
+}
+#undef HSTAMP
 
 // ------------------------------------------------------------------------------------------------
 // backward recurrence, t = S-1..1, N = 32*NR4W.  grid (N/16, ceil(B/COLS)), 512 threads.
@@ -1589,6 +2095,7 @@ bool persistent_supported(int N, int B, int n_cus, bool fused) {
     size_t fwd_grid = 0;
     if (fwd_uses_8col_form(N, B, n_cus)) {
         fwd_grid = (size_t)(N / 16) * ((B + 7) / 8);
+        if (N == 512 && blocks_per_cu(k_fwd_persistent6<false>, FWD4_THREADS) < 1) return false;
         switch (N / 256) {
 #define X(k) case k: fb = blocks_per_cu(k_fwd_persistent4<k, false>, FWD4_THREADS); break;
             X(1) X(2) X(4)
@@ -1721,6 +2228,23 @@ void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, flo
     }
 }
 
+// two-half form (k_fwd_persistent6): N = 512 on the grid of the 8-column form
+bool fwd_uses_two_half_form(int N, int B, int n_cus) { return N == 512 && fwd_uses_8col_form(N, B, n_cus); }
+void fwd_persistent6(const float4 *Ufwd5, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
+                     float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
+                     int poll_cfg, hipStream_t st, unsigned long long *stamps) {
+    const dim3 grid(N / 16, (B + 7) / 8), block(FWD4_THREADS);
+    if (stamps != nullptr)
+        hipLaunchKernelGGL((k_fwd_persistent6<false, true>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch,
+                           ring_base, S, B, poll_cfg, stamps);
+    else if (fast)
+        hipLaunchKernelGGL((k_fwd_persistent6<true>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch,
+                           ring_base, S, B, poll_cfg, nullptr);
+    else
+        hipLaunchKernelGGL((k_fwd_persistent6<false>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch,
+                           ring_base, S, B, poll_cfg, nullptr);
+}
+
 void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, float *H, unsigned short *Hb, float *C,
                          float *G, const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
                          bool fast, hipStream_t st) {
@@ -1753,6 +2277,24 @@ void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, 
 // ---- backward --------------------------------------------------------------------------------------------------------
 size_t bwd_ring_floats(int N, int B) { return (size_t)HX_RING * 4 * N * B; }
 int bwd_ring_advance(int ring_base, int S) { return (ring_base - (S - 1)) & (HX_RING - 1); }
+
+// two-half form of the backward recurrence (k_bwd_halves): N = 512, 8-column groups, gradient sums not fused
+bool bwd_halves_supported(int N, int B, int n_cus) {
+    if (N != 512 || bwd_group_cols(N, B, n_cus) != 8) return false;
+    const size_t grid = (size_t)(N / 16) * ((B + 7) / 8);
+    return blocks_per_cu(k_bwd_halves<false>, BWDH_THREADS) >= 1 && grid <= (size_t)n_cus;
+}
+void bwd_halves(const float4 *Ubwd5, float *DG, const float *DHy, const float *G, const float *C, float *DGx, unsigned *cnt,
+                unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int cfg, hipStream_t st,
+                unsigned long long *stamps) {
+    const dim3 grid(N / 16, (B + 7) / 8), block(BWDH_THREADS);
+    if (stamps != nullptr)
+        hipLaunchKernelGGL((k_bwd_halves<true>), grid, block, 0, st, Ubwd5, DG, DHy, G, C, DGx, cnt, abortp, epoch, ring_base, S, B, cfg,
+                           stamps);
+    else
+        hipLaunchKernelGGL((k_bwd_halves<false>), grid, block, 0, st, Ubwd5, DG, DHy, G, C, DGx, cnt, abortp, epoch, ring_base, S, B,
+                           cfg, nullptr);
+}
 
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,
                     const int32_t *xi, float *gpart, const float *Why, const float *dY, unsigned *cnt, unsigned *abortp,

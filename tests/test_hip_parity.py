@@ -186,6 +186,32 @@ def test_backward_data_as_flag_handoff_matches_oracle(oracle32, monkeypatch):
     L.close()
 
 
+def test_backward_two_half_form_matches_oracle(oracle32, monkeypatch):
+    """LSTM_HIP_BWD_HALVES=1 with unfused gradient sums (read per handle at create): each workgroup of the backward
+    recurrence advances its eight columns as two alternating 4-column recurrences (k_bwd_halves, N = 512 only).  Same
+    window, same tolerances, ragged batch (B = 60: the last group has a padded half), ring reuse across launches."""
+    import lstm_hip
+    from oracle_lib import Oracle
+    N, S, B = 512, 11, 60
+    monkeypatch.setenv("LSTM_HIP_BWD_HALVES", "1")
+    L = lstm_hip.Lstm(N, S, B, flags=lstm_hip.NO_FUSED_GRADS)
+    monkeypatch.delenv("LSTM_HIP_BWD_HALVES")
+    orc = Oracle("f32_omp")
+    for rep in range(4):
+        P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=400 + rep, empty=((1, rep),))
+        fw = orc.forward(N, 256, S, B, P, xi, ti, h0, c0)
+        dref = orc.backward(N, 256, S, B, P, xi, ti, fw)
+        L.set_params(P)
+        L.set_state(0, h0, c0)
+        L.set_window(xi, ti)
+        L.forward()
+        assert abs(L.loss() - fw["loss_bits"]) <= LOSS_TOL * (S - 1)
+        L.backward()
+        rep_ = gu.grads_report(L.get_grads(), dref, N)
+        assert max(rep_.values()) <= GRAD_TOL, (rep, rep_)
+    L.close()
+
+
 def test_dense_one_hot_inputs_entry_point(oracle32):
     """lstm_hip_set_inputs_dense = copy_inputs_to_device (OV/lstm_eigen_class_CUDA/cu_lstm.h:364-377) with the reference's
     own operands: the dense one-hot x[t], target[t] and h[0], c[0].  Same window as through the index form, bit for bit;

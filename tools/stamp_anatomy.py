@@ -18,7 +18,7 @@ import lstm_hip  # noqa: E402
 from bench import synthetic_text  # noqa: E402
 
 N, S, B = 512, 100, 64
-L = lstm_hip.Lstm(N, S, B, flags=lstm_hip.DEBUG_STAMPS)
+L = lstm_hip.Lstm(N, S, B, flags=lstm_hip.DEBUG_STAMPS | int(os.environ.get("STAMP_FLAGS", "0")))
 L.set_params(lstm_hip.init_params(lstm_hip.MT19937Normal(1), N))
 text = synthetic_text(200000)
 L.set_text(text)
@@ -52,6 +52,40 @@ for wg in range(2):
         ("   h_t published (this workgroup) -> issue of wave 3's successful poll", s[t + 1, 13] - s[t, 3]),
         ("   issue -> return of that poll (load round trip)", s[t + 1, 9] - s[t + 1, 13]),
     ])
+
+if os.environ.get("LSTM_HIP_FWD_HALVES", "1") != "0":   # two-half form: wave 3 also stamps half B (slots 5, 6, 7)
+    for wg in range(2):
+        s = st[wg]
+        t = np.arange(3, S - 1)
+        show(f"forward two-half form, workgroup {wg}: product wave 3 around the step", [
+            ("half A: poll", s[t, 9] - s[t, 8]), ("half A: 64 MFMA", s[t, 10] - s[t, 9]),
+            ("half A: LDS + barrier X", s[t, 11] - s[t, 10]),
+            ("half B: poll", s[t, 5] - s[t, 11]), ("half B: 64 MFMA", s[t, 6] - s[t, 5]),
+            ("half B: LDS + barrier Y", s[t, 7] - s[t, 6]),
+            ("gating wave 8 (half A): X released -> published", s[t, 3] - s[t, 1]),
+            ("half A published -> wave 3's next half-A poll complete", s[t + 1, 9] - s[t, 3]),
+        ])
+
+if os.environ.get("LSTM_HIP_BWD_HALVES", "0") != "0":   # two-half backward form (needs STAMP_FLAGS=64: unfused sums)
+    for wg in (2, 3):
+        s = st[wg]
+        t = np.arange(S - 5, 3, -1)
+        show(f"backward two-half form, workgroup {wg - 2}: {np.median(s[t - 1, 8] - s[t, 8]):.0f} cycles per step", [
+            ("product wave 3, half A: fragments checked / polled", s[t, 9] - s[t, 8]),
+            ("product wave 3, half A: 64 MFMA + next requests issued", s[t, 10] - s[t, 9]),
+            ("product wave 3, half A: sums to LDS + count", s[t, 11] - s[t, 10]),
+            ("product wave 3, half B: fragments checked / polled", s[t, 5] - s[t, 11]),
+            ("product wave 3, half B: 64 MFMA + next requests issued", s[t, 6] - s[t, 5]),
+            ("product wave 3, half B: sums to LDS + count", s[t, 7] - s[t, 6]),
+            ("elementwise wave 8: operands requested -> count complete", s[t, 1] - s[t, 0]),
+            ("elementwise wave 8: fold (32 LDS reads) + elementwise + transpose", s[t, 2] - s[t, 1]),
+            ("elementwise wave 8: s_waitcnt vmcnt(0)", s[t, 3] - s[t, 2]),
+            ("elementwise wave 8: publish + reset + DG store issued", s[t, 4] - s[t, 3]),
+            ("count complete -> dg_t published (on the chain)", s[t, 3] - s[t, 1]),
+            ("dg_t published -> next count complete (on the chain)", s[t - 1, 1] - s[t, 3]),
+            ("   dg_t published -> wave 3's half-A fragments complete", s[t - 1, 9] - s[t, 3]),
+        ])
+    sys.exit(0)
 
 df = os.environ.get("LSTM_HIP_BWD_HANDOFF", "c")[0] == "f"
 for wg in (2, 3):
