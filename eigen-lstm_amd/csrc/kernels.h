@@ -66,12 +66,12 @@ bool fwd_uses_two_half_form(int N, int B, int n_cus);
 void fwd_persistent6(const float4 *Ufwd5, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
                      int poll_cfg, hipStream_t st, unsigned long long *stamps = nullptr);
-// two-half form of the backward recurrence (N = 512, 8-column groups, unfused): Ubwd5 image (pack_U / adagrad with bit 1 of
-// half_forms), dg ring DGx as for the data-as-flag hand-off
-bool bwd_halves_supported(int N, int B, int n_cus);
-void bwd_halves(const float4 *Ubwd5, float *DG, const float *DHy, const float *G, const float *C, float *DGx, unsigned *cnt,
-                unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int cfg, hipStream_t st,
-                unsigned long long *stamps = nullptr);
+// two-half form of the backward recurrence (N = 512, 8-column groups): Ubwd5 image (pack_U / adagrad with bit 1 of
+// half_forms), dg ring DGx as for the data-as-flag hand-off; computes Why^T dy itself; gpart != null: fused mode as below
+bool bwd_halves_supported(int N, int B, int n_cus, bool fused);
+void bwd_halves(const float4 *Ubwd5, float *DG, const float *Why, const float *dY, const float *G, const float *C, const float *H,
+                const int32_t *xi, float *gpart, float *DGx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N,
+                int S, int B, int cfg, hipStream_t st, unsigned long long *stamps = nullptr);
 // gpart != null (8-column groups only): fused mode.  The recurrence then also produces DHy on the fly from
 // Why and dY (DHy is not read), and leaves per-column-group partial blocks [dW | - | db | dWhy]
 // (bwd_partial_floats(N) floats each) to be folded in group order; H and xi are read as well.

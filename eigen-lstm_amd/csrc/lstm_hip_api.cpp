@@ -89,7 +89,7 @@ struct lstm_hip_ctx {
     int T = 0; // (S-1)*B columns in the time-batched matrices
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr; // the early part of the gradient all-reduce runs here, beside the dU product on `st`
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
     bool fold_pending = false;  // the backward pass left the gradient in pieces for Adagrad to sum (single-GPU loop)
     int n_slabs_dU = 0;         // ... with this many dU slabs (0: dU is final in dP)
     bool in_loop = false;       // inside lstm_hip_train_windows: nobody reads the gradient block between backward and Adagrad
@@ -111,6 +111,7 @@ struct lstm_hip_ctx {
     float4 *Ufwd = nullptr, *Ubwd = nullptr;
     float4 *Ubwd4 = nullptr; // weight image of the 4x4x1 backward form (kernels.hip, k_pack_U), when bwd_uses_m4
     float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel (fwd_uses_8col_form) or, fwd_cols4, of the two-half one
+    bool side_stream = true; // LSTM_HIP_NO_SIDE_STREAM=1 (per handle): keep the whole window on one stream
     int bwd_halves = 0;      // 1: backward recurrence likewise (k_bwd_halves; LSTM_HIP_BWD_HALVES=1, unfused gradient sums)
     int fwd_cols4 = 0;       // 1: forward recurrence as two alternating 4-column halves per workgroup (k_fwd_persistent6)
     float *Hx = nullptr;     // 8-column forward form: ring of hand-off slots (data-as-flag), sentinel-filled
@@ -310,9 +311,19 @@ int do_backward(lstm_hip_ctx *h) {
     if (h->bf16) { // DHy = Why^T * dY on bf16 operands: both already have the contraction index m contiguous
         RUN(K_GEMM_DHY, (pack_bf16(dY, (size_t)T * 256, h->dYb, h->st),
                          gemm_bf16(N, T, 256, h->Why_b, 256, h->dYb, 256, h->DHy + (size_t)N * B, N, 1, nullptr, h->st)));
-    } else if (!fused)
+    } else if (!fused && !h->bwd_halves) // (the two-half backward form computes Why^T dy itself)
         RUN(K_GEMM_DHY, gemm(true, false, N, T, 256, h->P + h->pl.Why, 256, dY, 256, h->DHy + (size_t)N * B, N, 1, nullptr,
                              h->st));
+    // Unfused two-half form, single GPU: the sums that do not feed the recurrence run on st2 beside it -- the column sort of
+    // the dW pass and dWhy = dY H^T while the recurrence runs (one workgroup per CU leaves room), the dW / db sums beside
+    // the dU product.  (Profiling runs keep everything on `st`, one timed launch after the other.)
+    const bool side = h->bwd_halves && !fused && h->side_stream && !h->comm && !h->profiling;
+    if (side) {
+        HIP_TRY(hipEventRecord(h->ev_fork, h->st));
+        HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+        dW_sort(h->xi + B, T, G4, h->dw_scratch, h->st2);
+        gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256, h->splits_dWhy, h->slabs, h->st2);
+    }
     unsigned *cb = h->cnt + h->cnt_bytes / sizeof(unsigned);
     if (h->persistent) {
         if (h->bwd_epoch >= (1u << 26)) {
@@ -325,8 +336,9 @@ int do_backward(lstm_hip_ctx *h) {
                                               h->xi, fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp,
                                               h->bwd_epoch, N, S, B, h->bwd_cols, h->st, nullptr, h->DGb));
         } else if (h->bwd_halves) {
-            RUN(K_BWD_PERSIST, bwd_halves(h->Ubwd4, h->DG, h->DHy, h->G, h->C, h->DGx, cb, h->abortp, h->bwd_epoch, h->ring_base_b, N,
-                                          S, B, h->bwd_halves >> 1, h->st, h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr));
+            RUN(K_BWD_PERSIST, bwd_halves(h->Ubwd4, h->DG, h->P + h->pl.Why, dY, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr,
+                                          h->DGx, cb, h->abortp, h->bwd_epoch, h->ring_base_b, N, S, B, h->bwd_halves >> 1, h->st,
+                                          h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr));
             h->ring_base_b = bwd_ring_advance(h->ring_base_b, S);
         } else {
             RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd4 ? h->Ubwd4 : h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi,
@@ -351,7 +363,7 @@ int do_backward(lstm_hip_ctx *h) {
                           transpose_pack_bf16(h->H, S * B, N, N, h->Ht_b, h->SBpad, h->st),
                           gemm_bf16(256, N, h->Tpad, h->dYt_b, h->Tpad, h->Ht_b + B, h->SBpad, h->dP + h->pl.Why, 256,
                                     h->splits_dWhy, h->slabs, h->st)));
-    } else if (!fused)
+    } else if (!fused && !side)
         RUN(K_GEMM_DWHY, gemm(false, true, 256, N, T, dY, 256, h->H + (size_t)N * B, N, h->dP + h->pl.Why, 256,
                               h->splits_dWhy, h->slabs, h->st));
     // dW, db                           R/lstm.cc:251-252
@@ -367,6 +379,11 @@ int do_backward(lstm_hip_ctx *h) {
         RUN(K_DW_DB, (gemm_fold(h->gpart, NGb, G4 * 256, 1, h->dP + h->pl.W, G4 * 256, h->st, psz),
                       gemm_fold(h->gpart + (size_t)G4 * 256 + (size_t)G4 * N, NGb, G4 + 256 * N, 1, h->dP + h->pl.b,
                                 G4 + 256 * N, h->st, psz)));
+    } else if (side) {
+        HIP_TRY(hipEventRecord(h->ev_mid, h->st)); // DG is complete
+        HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_mid, 0));
+        dW_sums(h->DG + (size_t)G4 * B, T, G4, h->dP + h->pl.W, h->dP + h->pl.b, h->dw_scratch, h->st2);
+        HIP_TRY(hipEventRecord(h->ev_join, h->st2));
     } else {
         RUN(K_DW_DB, dW_db(h->DG + (size_t)G4 * B, h->xi + B, T, G4, h->dP + h->pl.W, h->dP + h->pl.b, h->dw_scratch, h->st));
     }
@@ -404,6 +421,7 @@ int do_backward(lstm_hip_ctx *h) {
         RUN(K_GEMM_DU, gemm(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->dP + h->pl.U, G4, h->splits_dU,
                             h->slabs_dU, h->st));
     }
+    if (side) HIP_TRY(hipStreamWaitEvent(h->st, h->ev_join, 0)); // the gradient block is complete on `st` from here
     return 0;
 }
 
@@ -578,7 +596,10 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
         // hand-off of the backward recurrence: sharded counters (default) or the data-as-flag ring ("flag"); read per handle
         const char *e = getenv("LSTM_HIP_BWD_HANDOFF");
         const char *bh = getenv("LSTM_HIP_BWD_HALVES");
-        h->bwd_halves = !(bh && atoi(bh) != 0 && !want_fused) ? 0 : (atoi(bh) | 1) * (int) bwd_halves_supported((int)N, (int)B, prop.multiProcessorCount);
+        h->side_stream = !(getenv("LSTM_HIP_NO_SIDE_STREAM") && atoi(getenv("LSTM_HIP_NO_SIDE_STREAM")));
+        // two-half form wherever it exists; "0" selects the one-recurrence form (A/B), other values are tuning bits (<< 1)
+        const int bhv = bh ? atoi(bh) : 5;
+        h->bwd_halves = bhv == 0 ? 0 : (bhv | 1) * (int)bwd_halves_supported((int)N, (int)B, prop.multiProcessorCount, want_fused);
         if ((e && e[0] == 'f') || h->bwd_halves) {
             ALLOC(h->DGx, bwd_ring_floats((int)N, (int)B));
             HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * bwd_ring_floats((int)N, (int)B)));
@@ -598,6 +619,7 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     HIP_TRY(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
     if (h->persistent && (cfg->flags & LSTM_HIP_DEBUG_STAMPS) && cfg->N == 512 && h->Hx && h->Ubwd4) ALLOC(h->stamps, 4 * S * 16);
     HIP_TRY(hipDeviceSynchronize());
     return 0;
@@ -618,7 +640,7 @@ int lstm_hip_destroy(lstm_hip_t *h) {
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    for (hipEvent_t e : {h->ev_fork, h->ev_join})
+    for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_mid})
         if (e) (void)hipEventDestroy(e);
     if (h->st2) (void)hipStreamDestroy(h->st2);
     if (h->st) (void)hipStreamDestroy(h->st);

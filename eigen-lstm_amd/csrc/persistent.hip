@@ -1203,7 +1203,7 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
 
 // ------------------------------------------------------------------------------------------------
 // backward recurrence, two half-groups per workgroup (N = 512, 8-column groups; the backward twin of k_fwd_persistent6).
-// grid (N/16, ceil(B/8)), 640 threads.  The eight columns of workgroup (kb, g) are two independent recurrences of four
+// grid (N/16, ceil(B/8)), 704 threads.  The eight columns of workgroup (kb, g) are two independent recurrences of four
 // columns, A and B: while A's dg_t is computed elementwise, published and fetched by the group, the eight product waves
 // run B's  dhnext = U^T dg_{t+1}  and the other way round.
 //   waves 0-7  product; K = 4N split over the waves (Kw = N/2 gate rows each), v_mfma_f32_4x4x1 with block = 4Y + z:
@@ -1213,258 +1213,559 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
 //              sixteen instructions; weights Ubwd5 (ubwd5_index), 64 registers; 64 instructions per half and step.
 //   wave 8 / 9 elementwise (R/lstm.cc:228-247,256) of half A / B: lane = column*16 + unit, folds the 8 x 4 (wave, Y)
 //              partial sums, publishes dg_t to the ring DGx (data-as-flag, as in k_bwd_persistent<.., DF>) and stores
-//              the plain DG the dU / dW products read after the launch.
-// No workgroup barrier in the loop (LDS count per half, partial sums double-buffered by step parity).
+//              the plain DG the dU product reads after the launch.  In the time it would otherwise wait for the next
+//              product it does the output-layer work of the NEXT step on the vector ALU (the matrix pipe belongs to the
+//              chain; the same work as 4x4x1 instructions in this wave measured +25 us a window):
+//                dhy_{t-1} = Why^T dy_{t-1}   (R/lstm.cc:228)   for its 16 units x 4 columns
+//                dWhy[:, units] += dy_{t-1} h_{t-1}^T (:226)    FUSE; 64 accumulators per lane
+//              as lane (m-quarter q, unit u): dy_{t-1} of the four columns is staged in LDS, Why[:, units] sits in LDS for
+//              the whole launch, each 16-byte LDS read of dy feeds 8 multiply-adds.
+//   wave 10    FUSE: dW[rows, x] += dg_t[rows, column] for the column's input byte x (R/lstm.cc:251): the [257][64] LDS
+//              table of k_bwd_persistent<.., FUSE>, fed through a double-buffered LDS copy of dg; db (:252) in the
+//              elementwise lanes' registers.  Partial blocks per column group go to gpart as there.
+// No workgroup barrier in the loop: LDS counters (s_done: partial sums in; s_stage / s_tab: dg copies for the dW wave).
 // ------------------------------------------------------------------------------------------------
-constexpr int BWDH_THREADS = 640;
+constexpr int BWDH_THREADS = 768;
+constexpr int BWDH_RED = 2 * 2 * 8 * 256, BWDH_YTMP = 256, BWDH_DHY = 4 * 128, BWDH_STAGE = 2 * 4 * 256;
+constexpr size_t bwdh_lds_bytes(bool fuse) {
+    return sizeof(float) * (size_t)(16 + BWDH_RED + BWDH_YTMP + BWDH_DHY + (fuse ? BWDH_STAGE + 257 * 64 : 0));
+}
 #define HSTAMP(wave, k)                                                                                        \
     if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
         stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = __builtin_amdgcn_s_memtime();
-template <bool STAMP = false>
-__global__ __launch_bounds__(BWDH_THREADS) void k_bwd_halves(const float4 *__restrict__ Ubwd5, float *DG,
-                                                             const float *__restrict__ DHy, const float *__restrict__ G,
-                                                             const float *__restrict__ C, float *DGx, unsigned *cnt,
-                                                             unsigned *abortp, unsigned epoch, int ring_base, int S, int B,
-                                                             int cfg, unsigned long long *stamps = nullptr) {
-    constexpr int N = 512, G4 = 4 * N, Kw = N / 2, NL = Kw / 64; // NL 16-byte loads per lane, half and step
-    constexpr int WS = 256;                                      // partial-sum image: [wave][column*16 + unit][Y]
-    __shared__ __attribute__((aligned(16))) float red[2][2][8 * WS]; // [half][step parity]
-    __shared__ int s_abort;
-    __shared__ unsigned s_done[2];
-    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int NBK = gridDim.x, NG = gridDim.y;
-    const int lin_ = blockIdx.x + NBK * blockIdx.y;
-    const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
-    const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DGx, (size_t)HX_RING * G4 * B * sizeof(float));
-    unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
+// The four roles are separate functions for readability (inlined); what they share comes through BwdhArgs (the kernel's
+// arguments) and the LDS block.  (Not inlined, the argument block is read through a generic pointer into vector registers
+// and every buffer access turns into a waterfall loop: 1.5 ms.)
+struct BwdhArgs {
+    const float4 *Ubwd5;
+    float *DG;
+    const float *Why, *dY, *G, *C, *H;
+    const int32_t *xi;
+    float *gpart, *DGx;
+    unsigned *cnt, *abortp;
+    unsigned epoch;
+    int ring_base, S, B, cfg;
+    unsigned long long *stamps;
+};
+constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, s_done[2], s_stage[2], s_dy, s_ol, s_tab
+#define BWDH_COMMON(p)                                                                                                          \
+    constexpr int N = 512, G4 = 4 * N, Kw = N / 2, NL = Kw / 64; /* NL 16-byte loads per lane, half and step */                 \
+    constexpr int WS = 256;                                      /* partial-sum image: [wave][column*16 + unit][Y] */           \
+    extern __shared__ __attribute__((aligned(16))) float lds[];                                                                 \
+    unsigned *sync_ = reinterpret_cast<unsigned *>(lds);                                                                        \
+    int *s_abort = reinterpret_cast<int *>(sync_);                                                                              \
+    unsigned *s_done = sync_ + 1, *s_stage = sync_ + 3, *s_dy = sync_ + 5, *s_ol = sync_ + 6, *s_tab = sync_ + 7;               \
+    float *red = lds + BWDH_SYNC;     /* [half][step parity][8 * WS] */                                                         \
+    float *ytmp = red + BWDH_RED;     /* wave 11: [column*16 + unit][k-class Y] of the half it is folding */                    \
+    float *dhyb = ytmp + BWDH_YTMP;   /* [step & 3][column][unit]: Why^T dy of the step */                                      \
+    float *stage = dhyb + BWDH_DHY;   /* FUSE: [half][step & 3][column][gate*16 + unit] */                                      \
+    float *dWt = stage + BWDH_STAGE;  /* FUSE: [257][64] */                                                                     \
+    const float4 *__restrict__ Ubwd5 = p.Ubwd5;                                                                                 \
+    float *DG = p.DG, *DGx = p.DGx, *gpart = p.gpart;                                                                           \
+    const float *__restrict__ Why = p.Why, *__restrict__ dY = p.dY, *__restrict__ G = p.G, *__restrict__ C = p.C,               \
+                             *__restrict__ H = p.H;                                                                             \
+    const int32_t *__restrict__ xi = p.xi;                                                                                      \
+    unsigned *cnt = p.cnt, *abortp = p.abortp;                                                                                  \
+    const unsigned epoch = p.epoch;                                                                                             \
+    const int ring_base = p.ring_base, S = p.S, B = p.B, cfg = p.cfg;                                                           \
+    unsigned long long *stamps = p.stamps;                                                                                      \
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;                                                                    \
+    const int NBK = gridDim.x, NG = gridDim.y;                                                                                  \
+    const int lin_ = blockIdx.x + NBK * blockIdx.y;                                                                             \
+    const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;                    \
+    const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DGx, (size_t)HX_RING * G4 * B * sizeof(float));                                \
+    unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;                                                               \
+    /* a wave that gives up: the abort word ends the launch everywhere, the LDS word releases this workgroup's other waves */   \
+    auto give_up = [&]() {                                                                                                      \
+        if (l == 0) {                                                                                                           \
+            __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                         \
+            __hip_atomic_store(s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                                     \
+        }                                                                                                                       \
+    };                                                                                                                          \
+    auto lds_wait = [&](unsigned *word, unsigned want) -> bool { /* bounded like every other spin of these kernels */           \
+        for (int spins = 0; spins <= SPIN_LIMIT; spins++) {                                                                     \
+            if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) {                              \
+                asm volatile("" ::: "memory");                                                                                  \
+                return true;                                                                                                    \
+            }                                                                                                                   \
+            if (__hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;                       \
+            __builtin_amdgcn_s_sleep(1);                                                                                        \
+        }                                                                                                                       \
+        return false;                                                                                                           \
+    };                                                                                                                          \
+    /* FUSE, after the loops (every wave, at the end of its role): barrier, the dW table and the db / dWhy partial blocks */    \
+    float *base = FUSE ? gpart + (size_t)g * ((size_t)G4 * 256 + (size_t)G4 * N + G4 + (size_t)256 * N) : nullptr;              \
+    float *dbs = red; /* epilogue scratch in `red` (free then): [column 0..7][gate][unit] */                                    \
+    auto table_out = [&]() { /* dW partial: table row r = gate*16 + unit  ->  gradient row gate*N + 16*kb + unit */             \
+        const int pid = tid < 512 ? tid : tid - 128; /* the product waves and wave 10 (threads 640-703): 576 threads */         \
+        for (int i = pid; i < 256 * 64; i += 576) {                                                                             \
+            const int x = i >> 6, r = i & 63;                                                                                   \
+            base[(size_t)x * G4 + (r >> 4) * N + 16 * kb + (r & 15)] = dWt[i];                                                  \
+        }                                                                                                                       \
+    };                                                                                                                          \
+    (void)Ubwd5, (void)DG, (void)Why, (void)dY, (void)G, (void)C, (void)H, (void)xi, (void)epoch, (void)ring_base, (void)cfg,   \
+        (void)stamps, (void)NBK, (void)rDG, (void)xcc_tab, (void)s_done, (void)s_stage, (void)s_dy, (void)s_ol, (void)s_tab,    \
+        (void)ytmp, (void)dhyb, (void)stage, (void)dWt, (void)base, (void)dbs, (void)Kw, (void)NL, (void)WS,         \
+        (void)kb, (void)w;
+
+template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_product(const BwdhArgs &p) {
+    BWDH_COMMON(p)
+    bool live = true; // false: this wave has left the loop on an abort
+    __builtin_amdgcn_s_setprio(2); // below the elementwise waves (3), above the side waves 10 and 11 (0)
+    // ---------------- product waves ----------------
+    const int lY = l >> 4, lz = (l >> 2) & 3, li = l & 3;
+    float4 a[4 * NL];
+#pragma unroll
+    for (int i = 0; i < 4 * NL; i++) a[i] = Ubwd5[(((size_t)kb * 8 + w) * (4 * NL) + i) * 64 + l];
+    int cofs[2]; // float offset of this lane's first fragment inside a step slot
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+        const int c = 8 * g + 4 * hf + li, cc_ = c < B ? c : B - 1;
+        cofs[hf] = cc_ * G4 + Kw * w + 16 * lY + 4 * lz;
+    }
+    // hint: lane i < Kw/16 looks at producer workgroup i of this wave's K-slice (one gate, Kw consecutive units): the
+    // 16 bytes its elementwise wave stores from its last lane (column 3 of the half, units 12-15)
+    const bool use_hint = (cfg & 1) != 0, spec_a = (cfg & 2) == 0;
+    int hint_ofs[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+        const int c = 8 * g + 4 * hf + 3, cc_ = c < B ? c : B - 1;
+        hint_ofs[hf] = cc_ * G4 + Kw * w + 16 * (l & (Kw / 16 - 1)) + 12;
+    }
+    float4 bq[2][NL];
+    // (epilogue of this role: at the end of the branch)
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+        for (int m = 0; m < NL; m++) bq[hf][m] = float4{0.f, 0.f, 0.f, 0.f};
+    // step t consumes dg_{t+1} from slot(t+1); the first product step is t = S-2.  Requests run one half-step ahead.
+    auto slot_off = [&](int tt, int hf) { return (int)(((size_t)((tt + ring_base) & (HX_RING - 1)) * B * G4 + cofs[hf]) * sizeof(float)); };
+    for (int t = S - 2; t >= 1 && live; t--) {
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            if (!live) break;
+            if (hf == 0) { HSTAMP(3, 8) }
+            bool good = (t < S - 2 && spec_a) || hf == 1; // (S-2, A) has not been requested yet
+            if (good)
+#pragma unroll
+                for (int m = 0; m < NL; m++) good = good && hx_ready(bq[hf][m]);
+            if (!__all(good)) {
+                const int off = slot_off(t + 1, hf);
+                if (use_hint) { // one request per wave until the last-stored piece of each producer of this K-slice is in
+                    const int hoff = (int)(((size_t)((t + 1 + ring_base) & (HX_RING - 1)) * B * G4 + hint_ofs[hf]) * sizeof(float));
+                    for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                        float4 hv = {0.f, 0.f, 0.f, 0.f};
+                        if (l < Kw / 16) hv = ld_sc1(rDG, hoff);
+                        if (__all(hx_ready(hv))) break;
+                        if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                bool ok = false;
+                for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                    bool gd = true;
+#pragma unroll
+                    for (int m = 0; m < NL; m++) bq[hf][m] = ld_sc1(rDG, off + 256 * m);
+#pragma unroll
+                    for (int m = 0; m < NL; m++) gd = gd && hx_ready(bq[hf][m]);
+                    if (__all(gd)) {
+                        ok = true;
+                        break;
+                    }
+                    if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                }
+                if (!ok) {
+                    give_up();
+                    live = false;
+                    break;
+                }
+            }
+            if (hf == 0) { HSTAMP(3, 9) } else { HSTAMP(3, 5) }
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+#define H_STEP(av, wq)                                              \
+c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.x, c0, 2, 0, 0); \
+c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.y, c1, 2, 1, 0); \
+c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.z, c2, 2, 2, 0); \
+c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.w, c3, 2, 3, 0);
+#pragma unroll
+            for (int m = 0; m < NL; m++) {
+                H_STEP(bq[hf][m].x, a[4 * m + 0])
+                H_STEP(bq[hf][m].y, a[4 * m + 1])
+                H_STEP(bq[hf][m].z, a[4 * m + 2])
+                H_STEP(bq[hf][m].w, a[4 * m + 3])
+            }
+#undef H_STEP
+            __builtin_amdgcn_sched_barrier(0);
+            // the other half's next fragments: (t, B) behind A's product, (t-1, A) behind B's
+            {
+                const int tn = hf == 0 ? t : t - 1;
+                if (tn >= 1 && (hf == 0 || spec_a)) {
+                    const int noff = slot_off(tn + 1, hf ^ 1);
+#pragma unroll
+                    for (int m = 0; m < NL; m++) bq[hf ^ 1][m] = ld_sc1(rDG, noff + 256 * m);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (hf == 0) { HSTAMP(3, 10) } else { HSTAMP(3, 6) }
+            float *rp = red + (hf * 2 + (t & 1)) * (8 * WS) + w * WS + 4 * (4 * lz + li) + lY; // lane (Y, z, j = li): unit 4z + j
+#pragma unroll
+            for (int r = 0; r < 4; r++) rp[64 * r] = (c0[r] + c1[r]) + (c2[r] + c3[r]); // register r = column r of the half
+            asm volatile("" ::: "memory");
+            if (l == 0) __hip_atomic_fetch_add(&s_done[hf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (hf == 0) { HSTAMP(3, 11) } else { HSTAMP(3, 7) }
+        }
+    }
+    if (FUSE) {
+        __syncthreads();
+        if (__hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return; // the host reports the abort
+        table_out();
+        __syncthreads();
+        if (w == 0) { // db partial: the eight columns in order
+            const int gt = l >> 4, rj = l & 15;
+            float sum = 0.0f;
+            for (int c = 0; c < 8; c++) sum += dbs[(c * 4 + gt) * 16 + rj];
+            base[(size_t)G4 * 256 + (size_t)G4 * N + gt * N + 16 * kb + rj] = sum;
+        }
+    }
+}
+template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_elementwise(const BwdhArgs &p) {
+    BWDH_COMMON(p)
+    // ---------------- elementwise waves: wave 8 half A, wave 9 half B; lane = column*16 + unit ----------------
+    const int hf = w - 8;
+    __builtin_amdgcn_s_setprio(3);
+    const int cc = l >> 4, jj = l & 15;
+    const int ecol = 8 * g + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
+    const int j = 16 * kb + jj;
+    float dcn = 0.0f; // dcnext, R/lstm.cc:217
+    bool local_pub = false;
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float *rp0 = red + hf * 2 * (8 * WS) + 4 * (cc * 16 + jj);
+    // operands that do not depend on the chain are requested a step ahead
+    float ig, og, fg, ug, cv, cp;
+    auto fetch = [&](int tu) {
+        const float *gc = G + ((size_t)tu * B + ecolc) * G4 + j;
+        ig = gc[0], og = gc[N], fg = gc[2 * N], ug = gc[3 * N];
+        cv = C[((size_t)tu * B + ecolc) * N + j], cp = C[((size_t)(tu - 1) * B + ecolc) * N + j];
+    };
+    fetch(S - 1);
+    for (int t = S - 1; t >= 1; t--) {
+        HSTAMP(8, 0)
+        float dhn = 0.0f;
+        if (t < S - 1) {
+            if (!lds_wait(&s_done[hf], 8u * (unsigned)(S - 1 - t))) {
+                give_up();
+                break;
+            }
+            HSTAMP(8, 1)
+            const float *rp = rp0 + (t & 1) * (8 * WS);
+            float4 sm = *reinterpret_cast<const float4 *>(rp); // the four k-classes Y of a wave side by side
+#pragma unroll
+            for (int ww = 1; ww < 8; ww++) {
+                const float4 v = *reinterpret_cast<const float4 *>(rp + ww * WS);
+                sm.x += v.x;
+                sm.y += v.y;
+                sm.z += v.z;
+                sm.w += v.w;
+            }
+            dhn = (sm.x + sm.y) + (sm.z + sm.w);
+        }
+        // the output-layer term of this step: wave 11 runs ahead of the chain, so this does not wait in practice
+        if (!lds_wait(s_ol, (unsigned)(S - t))) {
+            give_up();
+            break;
+        }
+        const float dhy = dhyb[(t & 3) * 128 + (4 * hf + cc) * 16 + jj];
+        if (XCD_LOCAL && t == S - 2) { // every workgroup of the group has published dg_{S-1}, its XCC id before it
+            unsigned mine = 0;
+            bool same = true;
+            if (l < NBK) {
+                mine = __hip_atomic_load(xcc_tab + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                same = (mine >> 4) == epoch;
+            }
+            const unsigned first = __builtin_amdgcn_readfirstlane(mine);
+            if (l < NBK) same = same && mine == first;
+            local_pub = (XCD_FORCE_LOCAL || __all(same)) && NBK <= 64;
+        }
+        const float dh = dhy + dhn;                         // R/lstm.cc:228
+        float dcv = dh * og + dcn;                          // :233
+        dcv = dcv * (1.0f - cv * cv);                       // :235
+        const float d_o = (dh * cv) * (og * (1.0f - og));   // :238,244
+        const float d_i = (dcv * ug) * (ig * (1.0f - ig));  // :239,244
+        const float d_f = (dcv * cp) * (fg * (1.0f - fg));  // :240,244
+        const float d_u = (dcv * ig) * (1.0f - ug * ug);    // :241,247
+        dcn = dcv * fg;                                     // :256
+        // 4x4 transpose over the four lanes of a quad by DPP: lane (column cc, unit jj = 4*tq + ta) ends up with gate ta
+        // of units 4*tq .. 4*tq+3, one 16-byte store
+        const int ta = jj & 3, tq = jj >> 2;
+        float t0 = d_i, t1 = d_o, t2 = d_f, t3 = d_u;
+        {
+            const float lo = (ta & 1) ? t0 : t1, hi = (ta & 1) ? t2 : t3;
+            const float rlo = dpp_f<0xB1>(lo), rhi = dpp_f<0xB1>(hi); // quad_perm [1,0,3,2]
+            if (ta & 1) {
+                t0 = rlo;
+                t2 = rhi;
+            } else {
+                t1 = rlo;
+                t3 = rhi;
+            }
+            const float s0 = (ta & 2) ? t0 : t2, s1 = (ta & 2) ? t1 : t3;
+            const float r0 = dpp_f<0x4E>(s0), r1 = dpp_f<0x4E>(s1); // quad_perm [2,3,0,1]
+            if (ta & 2) {
+                t0 = r0;
+                t1 = r1;
+            } else {
+                t2 = r0;
+                t3 = r1;
+            }
+        }
+        HSTAMP(8, 2)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's older stores (the last reset) are complete
+        HSTAMP(8, 3)
+        if (ecol < B) {
+            const float4 v = {t0, t1, t2, t3};
+            const float4 vp = {hx_canon(v.x), hx_canon(v.y), hx_canon(v.z), hx_canon(v.w)};
+            const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
+                                 __uint_as_float(HX_SENT)};
+            const size_t within = (size_t)ecol * G4 + ta * N + 16 * kb + 4 * tq;
+            const size_t e_pub = (size_t)((t + ring_base) & (HX_RING - 1)) * B * G4 + within;
+            const size_t e_rst = (size_t)((t - 2 + ring_base) & (HX_RING - 1)) * B * G4 + within;
+            if (XCD_LOCAL && local_pub) {
+                *reinterpret_cast<float4 *>(DGx + e_pub) = vp;
+                *reinterpret_cast<float4 *>(DGx + e_rst) = sent;
+            } else {
+                st_sc1(vp, rDG, (int)(e_pub * sizeof(float)));
+                st_sc1(sent, rDG, (int)(e_rst * sizeof(float)));
+            }
+            *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
+        }
+        HSTAMP(8, 4)
+        if (t >= 2) fetch(t - 1);
+        if (FUSE) {
+            if (ecol < B) { // db += dg, R/lstm.cc:252
+                dbacc[0] += d_i;
+                dbacc[1] += d_o;
+                dbacc[2] += d_f;
+                dbacc[3] += d_u;
+            }
+            // dg_t for the dW wave (four copies deep; s_tab counts the steps that wave has finished)
+            if (t + 4 <= S - 1 && !(cfg & 32) && !lds_wait(s_tab, (unsigned)(S - (t + 4)))) {
+                give_up();
+                break;
+            }
+            float *sp = stage + (hf * 4 + (t & 3)) * 256 + cc * 64 + jj;
+            sp[0] = d_i;
+            sp[16] = d_o;
+            sp[32] = d_f;
+            sp[48] = d_u;
+            asm volatile("" ::: "memory");
+        }
+        // step t done here: its dhy slot is free, its dg copy is in place
+        if (l == 0) __hip_atomic_fetch_add(&s_stage[hf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (FUSE) {
+        __syncthreads();
+        if (__hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++) dbs[((4 * hf + cc) * 4 + gt) * 16 + jj] = dbacc[gt]; // through `red` (free now)
+        __syncthreads();
+    }
+}
+template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_output_layer(const BwdhArgs &p) {
+    BWDH_COMMON(p)
+    // ---------------- wave 11: the output-layer term dhy_t = Why^T dy_t (R/lstm.cc:228), ahead of the chain ----------------
+    // The product waves' arrangement with K = 256: lane (Y, z', i) loads dy_t[m = 64q + 16Y + 4z' + r][column 4*half + i]
+    // (16 bytes, q = 0..3), weights Why[m][unit 4z + j] in 64 registers, 64 instructions v_mfma_f32_4x4x1 per half; the four
+    // k-classes Y are folded through LDS.  Matrix instructions, but at the lowest priority and up to four steps ahead of the
+    // chain: they fill gaps the product waves leave.  (On the vector ALU with dy staged in LDS the same work measured 12 600
+    // cycles a step -- an LDS round trip per group of reads -- and held the whole recurrence back.)
+    const int lY = l >> 4, lz = (l >> 2) & 3, li = l & 3;
+    float4 wy[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float *wp = Why + (size_t)(16 * kb + 4 * lz + li) * 256 + 64 * q + 16 * lY; // + 4z' + r
+        const float4 v0 = *reinterpret_cast<const float4 *>(wp), v1 = *reinterpret_cast<const float4 *>(wp + 4);
+        const float4 v2 = *reinterpret_cast<const float4 *>(wp + 8), v3 = *reinterpret_cast<const float4 *>(wp + 12);
+        wy[4 * q + 0] = float4{v0.x, v1.x, v2.x, v3.x};
+        wy[4 * q + 1] = float4{v0.y, v1.y, v2.y, v3.y};
+        wy[4 * q + 2] = float4{v0.z, v1.z, v2.z, v3.z};
+        wy[4 * q + 3] = float4{v0.w, v1.w, v2.w, v3.w};
+    }
+    int yofs[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+        const int c = 8 * g + 4 * hf + li;
+        yofs[hf] = (c < B ? c : B - 1) * 256 + 16 * lY + 4 * lz;
+    }
+    // (named registers, not arrays: see the note on scratch memory in the git history of this file)
+    float4 a0, a1, a2, a3, b0, b1, b2, b3; // dy of the step worked on next, halves A and B; requested a step ahead
+#define OL_REQUEST(tu)                                                   \
+    do { /* dY holds steps 1.. at column (t-1)*B + b */                  \
+        const float *dp_ = dY + (size_t)((tu) - 1) * B * 256;            \
+        a0 = *reinterpret_cast<const float4 *>(dp_ + yofs[0]);           \
+        a1 = *reinterpret_cast<const float4 *>(dp_ + yofs[0] + 64);      \
+        a2 = *reinterpret_cast<const float4 *>(dp_ + yofs[0] + 128);     \
+        a3 = *reinterpret_cast<const float4 *>(dp_ + yofs[0] + 192);     \
+        b0 = *reinterpret_cast<const float4 *>(dp_ + yofs[1]);           \
+        b1 = *reinterpret_cast<const float4 *>(dp_ + yofs[1] + 64);      \
+        b2 = *reinterpret_cast<const float4 *>(dp_ + yofs[1] + 128);     \
+        b3 = *reinterpret_cast<const float4 *>(dp_ + yofs[1] + 192);     \
+    } while (0)
+#define Y_STEP(av, wq)                                              \
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.x, c0, 2, 0, 0); \
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.y, c1, 2, 1, 0); \
+    c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.z, c2, 2, 2, 0); \
+    c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.w, c3, 2, 3, 0);
+#define OL_HALF(d0, d1, d2, d3, hf)                                                                             \
+    do {                                                                                                        \
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;                                             \
+        Y_STEP(d0.x, wy[0]) Y_STEP(d0.y, wy[1]) Y_STEP(d0.z, wy[2]) Y_STEP(d0.w, wy[3])                         \
+        Y_STEP(d1.x, wy[4]) Y_STEP(d1.y, wy[5]) Y_STEP(d1.z, wy[6]) Y_STEP(d1.w, wy[7])                         \
+        Y_STEP(d2.x, wy[8]) Y_STEP(d2.y, wy[9]) Y_STEP(d2.z, wy[10]) Y_STEP(d2.w, wy[11])                       \
+        Y_STEP(d3.x, wy[12]) Y_STEP(d3.y, wy[13]) Y_STEP(d3.z, wy[14]) Y_STEP(d3.w, wy[15])                     \
+        float *yp_ = ytmp + 4 * (4 * lz + li) + lY; /* lane (Y, z, j): unit 4z + j, register r = column r */    \
+        _Pragma("unroll") for (int r = 0; r < 4; r++) yp_[64 * r] = (c0[r] + c1[r]) + (c2[r] + c3[r]);          \
+        asm volatile("" ::: "memory");                                                                          \
+        const float4 v_ = *reinterpret_cast<const float4 *>(ytmp + 4 * l); /* lane = column*16 + unit */        \
+        asm volatile("" ::: "memory");                                                                          \
+        dst[64 * (hf) + l] = (v_.x + v_.y) + (v_.z + v_.w);                                                     \
+    } while (0)
+    OL_REQUEST(S - 1);
+    for (int tu = S - 1; tu >= 1; tu--) {
+        const int t = tu;
+        HSTAMP(11, 12)
+        // slot tu & 3 held the term of step tu+4: both elementwise waves must have read it
+        if (tu + 4 <= S - 1) {
+            const unsigned need = (unsigned)(S - (tu + 4));
+            if (!lds_wait(&s_stage[0], need) || !lds_wait(&s_stage[1], need)) {
+                give_up();
+                break;
+            }
+        }
+        HSTAMP(11, 13)
+        float *dst = dhyb + (tu & 3) * 128;
+        OL_HALF(a0, a1, a2, a3, 0);
+        OL_HALF(b0, b1, b2, b3, 1);
+        HSTAMP(11, 14)
+        if (tu >= 2) OL_REQUEST(tu - 1); // in flight until this wave comes round again
+        asm volatile("" ::: "memory");
+        if (l == 0) __hip_atomic_store(s_ol, (unsigned)(S - tu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        HSTAMP(11, 15)
+    }
+#undef OL_HALF
+#undef Y_STEP
+#undef OL_REQUEST
+    if (FUSE) {
+        __syncthreads();
+        __syncthreads();
+    }
+}
+template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_weight_sums(const BwdhArgs &p) {
+    BWDH_COMMON(p)
+    // ---------------- wave 10: the weight-gradient sums that stay in the workgroup ----------------
+    //   dW[:, x] += dg_t[:, column]  (R/lstm.cc:251)  one lane per row (gate*16 + unit) of the workgroup, [257][64] LDS table
+    //   dWhy[:, units] += dy_t h_t^T (R/lstm.cc:226)  v_mfma_f32_4x4x1, one instruction = one column c, 64 output rows m and
+    //       four units: D[i][j] += h_t[unit 4q + i][c] * dy_t[m = 64mg + lane][c], the h operand broadcast from block q of a
+    //       register that holds the 16 units in lanes 0-15 (CBSZ = 4 / ABID = q); 16 accumulators (mg, q), 128 instructions
+    //       a step at the lowest priority; operands straight from global memory, a step ahead.
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float hq[8], dq[8][4]; // h_tu[unit l & 15][column c] (zero for a padding column: no dWhy from it), dy_tu[64mg + l][column c]
+    auto prefetch = [&](int tu) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int col = 8 * g + c, colc = col < B ? col : B - 1;
+            hq[c] = col < B ? H[((size_t)tu * B + col) * N + 16 * kb + (l & 15)] : 0.0f;
+            const float *dp = dY + ((size_t)(tu - 1) * B + colc) * 256 + l; // dY holds steps 1.. at column (t-1)*B + b
+#pragma unroll
+            for (int mg = 0; mg < 4; mg++) dq[c][mg] = dp[64 * mg];
+        }
+    };
+    // input bytes of the eight columns: lane c < 8 loads column c's, a step ahead (a vector load on purpose: scalar loads
+    // share the LDS wait counter and would serialise with every LDS access below)
+    auto xfetch = [&](int tu) -> int {
+        const int col = 8 * g + (l & 7);
+        const int x = col < B ? xi[(size_t)tu * B + col] : -2;
+        return x == -1 ? 256 : x; // -1: empty input column -> bucket 256; -2: padding column, skipped
+    };
+    int xnext = xfetch(S - 1);
+    prefetch(S - 1);
+    for (int tu = S - 1; tu >= 1; tu--) {
+        const int xcur = xnext;
+        if (tu >= 2) xnext = xfetch(tu - 1);
+        if (!(cfg & 8)) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+#pragma unroll
+                for (int mg = 0; mg < 4; mg++) {
+                    acc[4 * mg + 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(hq[c], dq[c][mg], acc[4 * mg + 0], 4, 0, 0);
+                    acc[4 * mg + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(hq[c], dq[c][mg], acc[4 * mg + 1], 4, 1, 0);
+                    acc[4 * mg + 2] = __builtin_amdgcn_mfma_f32_4x4x1f32(hq[c], dq[c][mg], acc[4 * mg + 2], 4, 2, 0);
+                    acc[4 * mg + 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(hq[c], dq[c][mg], acc[4 * mg + 3], 4, 3, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tu >= 2) prefetch(tu - 1);
+        bool ok = true;
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            if (!ok) break;
+            if (!lds_wait(&s_stage[hf], (unsigned)(S - tu))) {
+                ok = false;
+                break;
+            }
+            const float *sg_ = stage + (hf * 4 + (tu & 3)) * 256;
+            float sv[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) sv[c] = sg_[c * 64 + l];
+#pragma unroll
+            for (int c = 0; c < 4; c++) { // columns in order (two may share an input byte): deterministic sums
+                const int x = __builtin_amdgcn_readlane(xcur, 4 * hf + c);
+                if (x >= 0) dWt[x * 64 + l] += sv[c];
+            }
+        }
+        if (!ok) {
+            give_up();
+            break;
+        }
+        asm volatile("" ::: "memory");
+        if (l == 0) __hip_atomic_store(s_tab, (unsigned)(S - tu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    if (__hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+    table_out();
+    // accumulator (mg, q): lane l = output row 64mg + l, register i = unit 4q + i
+    float *Yp = base + (size_t)G4 * 256 + (size_t)G4 * N + G4 + (size_t)(16 * kb) * 256 + l;
+#pragma unroll
+    for (int mg = 0; mg < 4; mg++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) Yp[(size_t)(4 * q + i) * 256 + 64 * mg] = acc[4 * mg + q][i];
+    __syncthreads();
+}
+template <bool FUSE, bool STAMP = false> __global__ __launch_bounds__(BWDH_THREADS) void k_bwd_halves(const BwdhArgs p) {
+    BWDH_COMMON(p)
     if (tid == 0) {
-        s_abort = 0;
+        *s_abort = 0;
         s_done[0] = s_done[1] = 0;
+        s_stage[0] = s_stage[1] = 0;
+        *s_dy = *s_ol = 0;
+        *s_tab = 0;
         if (XCD_LOCAL) {
             __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // visible before anything this workgroup publishes
         }
     }
+    if (FUSE)
+        for (int i = tid; i < 257 * 64; i += BWDH_THREADS) dWt[i] = 0.0f;
     __syncthreads();
-
-    if (w < 8) {
-        // ---------------- product waves ----------------
-        const int lY = l >> 4, lz = (l >> 2) & 3, li = l & 3;
-        float4 a[4 * NL];
-#pragma unroll
-        for (int i = 0; i < 4 * NL; i++) a[i] = Ubwd5[(((size_t)kb * 8 + w) * (4 * NL) + i) * 64 + l];
-        int cofs[2]; // float offset of this lane's first fragment inside a step slot
-#pragma unroll
-        for (int hf = 0; hf < 2; hf++) {
-            const int c = 8 * g + 4 * hf + li, cc_ = c < B ? c : B - 1;
-            cofs[hf] = cc_ * G4 + Kw * w + 16 * lY + 4 * lz;
-        }
-        // hint: lane i < Kw/16 looks at producer workgroup i of this wave's K-slice (one gate, Kw consecutive units): the
-        // 16 bytes its elementwise wave stores from its last lane (column 3 of the half, units 12-15)
-        const bool use_hint = (cfg & 1) != 0, spec_a = (cfg & 2) == 0;
-        int hint_ofs[2];
-#pragma unroll
-        for (int hf = 0; hf < 2; hf++) {
-            const int c = 8 * g + 4 * hf + 3, cc_ = c < B ? c : B - 1;
-            hint_ofs[hf] = cc_ * G4 + Kw * w + 16 * (l & (Kw / 16 - 1)) + 12;
-        }
-        float4 bq[2][NL];
-#pragma unroll
-        for (int hf = 0; hf < 2; hf++)
-#pragma unroll
-            for (int m = 0; m < NL; m++) bq[hf][m] = float4{0.f, 0.f, 0.f, 0.f};
-        // step t consumes dg_{t+1} from slot(t+1); the first product step is t = S-2.  Requests run one half-step ahead.
-        auto slot_off = [&](int tt, int hf) { return (int)(((size_t)((tt + ring_base) & (HX_RING - 1)) * B * G4 + cofs[hf]) * sizeof(float)); };
-        for (int t = S - 2; t >= 1; t--) {
-#pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-                if (hf == 0) { HSTAMP(3, 8) }
-                bool good = (t < S - 2 && spec_a) || hf == 1; // (S-2, A) has not been requested yet
-                if (good)
-#pragma unroll
-                    for (int m = 0; m < NL; m++) good = good && hx_ready(bq[hf][m]);
-                if (!__all(good)) {
-                    const int off = slot_off(t + 1, hf);
-                    if (use_hint) { // one request per wave until the last-stored piece of each producer of this K-slice is in
-                        const int hoff = (int)(((size_t)((t + 1 + ring_base) & (HX_RING - 1)) * B * G4 + hint_ofs[hf]) * sizeof(float));
-                        for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
-                            float4 hv = {0.f, 0.f, 0.f, 0.f};
-                            if (l < Kw / 16) hv = ld_sc1(rDG, hoff);
-                            if (__all(hx_ready(hv))) break;
-                            if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                    }
-                    bool ok = false;
-                    for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
-                        bool gd = true;
-#pragma unroll
-                        for (int m = 0; m < NL; m++) bq[hf][m] = ld_sc1(rDG, off + 256 * m);
-#pragma unroll
-                        for (int m = 0; m < NL; m++) gd = gd && hx_ready(bq[hf][m]);
-                        if (__all(gd)) {
-                            ok = true;
-                            break;
-                        }
-                        if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                    }
-                    if (!ok) {
-                        if (l == 0) {
-                            __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                        return;
-                    }
-                }
-                if (hf == 0) { HSTAMP(3, 9) } else { HSTAMP(3, 5) }
-                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
-#define H_STEP(av, wq)                                              \
-    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.x, c0, 2, 0, 0); \
-    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.y, c1, 2, 1, 0); \
-    c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.z, c2, 2, 2, 0); \
-    c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.w, c3, 2, 3, 0);
-#pragma unroll
-                for (int m = 0; m < NL; m++) {
-                    H_STEP(bq[hf][m].x, a[4 * m + 0])
-                    H_STEP(bq[hf][m].y, a[4 * m + 1])
-                    H_STEP(bq[hf][m].z, a[4 * m + 2])
-                    H_STEP(bq[hf][m].w, a[4 * m + 3])
-                }
-#undef H_STEP
-                __builtin_amdgcn_sched_barrier(0);
-                // the other half's next fragments: (t, B) behind A's product, (t-1, A) behind B's
-                {
-                    const int tn = hf == 0 ? t : t - 1;
-                    if (tn >= 1 && (hf == 0 || spec_a)) {
-                        const int noff = slot_off(tn + 1, hf ^ 1);
-#pragma unroll
-                        for (int m = 0; m < NL; m++) bq[hf ^ 1][m] = ld_sc1(rDG, noff + 256 * m);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (hf == 0) { HSTAMP(3, 10) } else { HSTAMP(3, 6) }
-                float *rp = red[hf][t & 1] + w * WS + 4 * (4 * lz + li) + lY; // lane (Y, z, j = li): unit 4z + j
-#pragma unroll
-                for (int r = 0; r < 4; r++) rp[64 * r] = (c0[r] + c1[r]) + (c2[r] + c3[r]); // register r = column r of the half
-                asm volatile("" ::: "memory");
-                if (l == 0) __hip_atomic_fetch_add(&s_done[hf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (hf == 0) { HSTAMP(3, 11) } else { HSTAMP(3, 7) }
-            }
-        }
-    } else {
-        // ---------------- elementwise waves: wave 8 half A, wave 9 half B; lane = column*16 + unit ----------------
-        const int hf = w - 8;
-        __builtin_amdgcn_s_setprio(3);
-        const int cc = l >> 4, jj = l & 15;
-        const int ecol = 8 * g + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
-        const int j = 16 * kb + jj;
-        float dcn = 0.0f; // dcnext, R/lstm.cc:217
-        bool local_pub = false;
-        const float *rp0 = red[hf][0] + 4 * (cc * 16 + jj);
-        for (int t = S - 1; t >= 1; t--) {
-            // operands that do not depend on the chain
-            const float *gc = G + ((size_t)t * B + ecolc) * G4 + j;
-            const float ig = gc[0], og = gc[N], fg = gc[2 * N], ug = gc[3 * N];
-            const float cv = C[((size_t)t * B + ecolc) * N + j], cp = C[((size_t)(t - 1) * B + ecolc) * N + j];
-            const float dhy = DHy[((size_t)t * B + ecolc) * N + j];
-            HSTAMP(8, 0)
-            float dhn = 0.0f;
-            if (t < S - 1) {
-                const unsigned want = 8u * (unsigned)(S - 1 - t);
-                bool in = false;
-                for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
-                    in = __hip_atomic_load(&s_done[hf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want;
-                    if (in || __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (!in) {
-                    if (l == 0) {
-                        __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    return;
-                }
-                asm volatile("" ::: "memory");
-                HSTAMP(8, 1)
-                const float *rp = rp0 + (t & 1) * (8 * WS);
-                float4 sm = *reinterpret_cast<const float4 *>(rp); // the four k-classes Y of a wave side by side
-#pragma unroll
-                for (int ww = 1; ww < 8; ww++) {
-                    const float4 v = *reinterpret_cast<const float4 *>(rp + ww * WS);
-                    sm.x += v.x;
-                    sm.y += v.y;
-                    sm.z += v.z;
-                    sm.w += v.w;
-                }
-                dhn = (sm.x + sm.y) + (sm.z + sm.w);
-            }
-            if (XCD_LOCAL && t == S - 2) { // every workgroup of the group has published dg_{S-1}, its XCC id before it
-                unsigned mine = 0;
-                bool same = true;
-                if (l < NBK) {
-                    mine = __hip_atomic_load(xcc_tab + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    same = (mine >> 4) == epoch;
-                }
-                const unsigned first = __builtin_amdgcn_readfirstlane(mine);
-                if (l < NBK) same = same && mine == first;
-                local_pub = (XCD_FORCE_LOCAL || __all(same)) && NBK <= 64;
-            }
-            const float dh = dhy + dhn;                         // R/lstm.cc:228
-            float dcv = dh * og + dcn;                          // :233
-            dcv = dcv * (1.0f - cv * cv);                       // :235
-            const float d_o = (dh * cv) * (og * (1.0f - og));   // :238,244
-            const float d_i = (dcv * ug) * (ig * (1.0f - ig));  // :239,244
-            const float d_f = (dcv * cp) * (fg * (1.0f - fg));  // :240,244
-            const float d_u = (dcv * ig) * (1.0f - ug * ug);    // :241,247
-            dcn = dcv * fg;                                     // :256
-            // 4x4 transpose over the four lanes of a quad by DPP: lane (column cc, unit jj = 4*tq + ta) ends up with gate ta
-            // of units 4*tq .. 4*tq+3, one 16-byte store
-            const int ta = jj & 3, tq = jj >> 2;
-            float t0 = d_i, t1 = d_o, t2 = d_f, t3 = d_u;
-            {
-                const float lo = (ta & 1) ? t0 : t1, hi = (ta & 1) ? t2 : t3;
-                const float rlo = dpp_f<0xB1>(lo), rhi = dpp_f<0xB1>(hi); // quad_perm [1,0,3,2]
-                if (ta & 1) {
-                    t0 = rlo;
-                    t2 = rhi;
-                } else {
-                    t1 = rlo;
-                    t3 = rhi;
-                }
-                const float s0 = (ta & 2) ? t0 : t2, s1 = (ta & 2) ? t1 : t3;
-                const float r0 = dpp_f<0x4E>(s0), r1 = dpp_f<0x4E>(s1); // quad_perm [2,3,0,1]
-                if (ta & 2) {
-                    t0 = r0;
-                    t1 = r1;
-                } else {
-                    t2 = r0;
-                    t3 = r1;
-                }
-            }
-            HSTAMP(8, 2)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's older stores (the last reset) are complete
-            HSTAMP(8, 3)
-            if (ecol < B) {
-                const float4 v = {t0, t1, t2, t3};
-                const float4 vp = {hx_canon(v.x), hx_canon(v.y), hx_canon(v.z), hx_canon(v.w)};
-                const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
-                                     __uint_as_float(HX_SENT)};
-                const size_t within = (size_t)ecol * G4 + ta * N + 16 * kb + 4 * tq;
-                const size_t e_pub = (size_t)((t + ring_base) & (HX_RING - 1)) * B * G4 + within;
-                const size_t e_rst = (size_t)((t - 2 + ring_base) & (HX_RING - 1)) * B * G4 + within;
-                if (XCD_LOCAL && local_pub) {
-                    *reinterpret_cast<float4 *>(DGx + e_pub) = vp;
-                    *reinterpret_cast<float4 *>(DGx + e_rst) = sent;
-                } else {
-                    st_sc1(vp, rDG, (int)(e_pub * sizeof(float)));
-                    st_sc1(sent, rDG, (int)(e_rst * sizeof(float)));
-                }
-                *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
-            }
-            HSTAMP(8, 4)
-        }
-    }
+    if (w < 8) bwdh_product<FUSE, STAMP>(p);
+    else if (w < 10) bwdh_elementwise<FUSE, STAMP>(p);
+    else if (w == 11) bwdh_output_layer<FUSE, STAMP>(p);
+    else if (FUSE) bwdh_weight_sums<FUSE, STAMP>(p);
 }
 #undef HSTAMP
 
@@ -2278,22 +2579,35 @@ void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, 
 size_t bwd_ring_floats(int N, int B) { return (size_t)HX_RING * 4 * N * B; }
 int bwd_ring_advance(int ring_base, int S) { return (ring_base - (S - 1)) & (HX_RING - 1); }
 
-// two-half form of the backward recurrence (k_bwd_halves): N = 512, 8-column groups, gradient sums not fused
-bool bwd_halves_supported(int N, int B, int n_cus) {
+// two-half form of the backward recurrence (k_bwd_halves): N = 512, 8-column groups
+bool bwd_halves_supported(int N, int B, int n_cus, bool fused) {
     if (N != 512 || bwd_group_cols(N, B, n_cus) != 8) return false;
     const size_t grid = (size_t)(N / 16) * ((B + 7) / 8);
-    return blocks_per_cu(k_bwd_halves<false>, BWDH_THREADS) >= 1 && grid <= (size_t)n_cus;
+    const int per_cu = fused ? blocks_per_cu(k_bwd_halves<true>, BWDH_THREADS, bwdh_lds_bytes(true))
+                             : blocks_per_cu(k_bwd_halves<false>, BWDH_THREADS, bwdh_lds_bytes(false));
+    return per_cu >= 1 && grid <= (size_t)n_cus;
 }
-void bwd_halves(const float4 *Ubwd5, float *DG, const float *DHy, const float *G, const float *C, float *DGx, unsigned *cnt,
-                unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int cfg, hipStream_t st,
-                unsigned long long *stamps) {
+void bwd_halves(const float4 *Ubwd5, float *DG, const float *Why, const float *dY, const float *G, const float *C, const float *H,
+                const int32_t *xi, float *gpart, float *DGx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N,
+                int S, int B, int cfg, hipStream_t st, unsigned long long *stamps) {
     const dim3 grid(N / 16, (B + 7) / 8), block(BWDH_THREADS);
-    if (stamps != nullptr)
-        hipLaunchKernelGGL((k_bwd_halves<true>), grid, block, 0, st, Ubwd5, DG, DHy, G, C, DGx, cnt, abortp, epoch, ring_base, S, B, cfg,
-                           stamps);
+    const bool fuse = gpart != nullptr;
+    const size_t lds = bwdh_lds_bytes(fuse);
+#define BH_GO(...)                                                                                                                  \
+    do {                                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_halves<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds);                                                                                        \
+        hipLaunchKernelGGL((k_bwd_halves<__VA_ARGS__>), grid, block, lds, st, args);                                                \
+    } while (0)
+    const BwdhArgs args = {Ubwd5, DG, Why, dY, G, C, H, xi, gpart, DGx, cnt, abortp, epoch, ring_base, S, B, cfg, stamps};
+    if (stamps != nullptr) {
+        if (fuse) BH_GO(true, true);
+        else BH_GO(false, true);
+    } else if (fuse)
+        BH_GO(true, false);
     else
-        hipLaunchKernelGGL((k_bwd_halves<false>), grid, block, 0, st, Ubwd5, DG, DHy, G, C, DGx, cnt, abortp, epoch, ring_base, S, B,
-                           cfg, nullptr);
+        BH_GO(false, false);
+#undef BH_GO
 }
 
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,

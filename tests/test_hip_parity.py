@@ -186,15 +186,17 @@ def test_backward_data_as_flag_handoff_matches_oracle(oracle32, monkeypatch):
     L.close()
 
 
-def test_backward_two_half_form_matches_oracle(oracle32, monkeypatch):
-    """LSTM_HIP_BWD_HALVES=1 with unfused gradient sums (read per handle at create): each workgroup of the backward
-    recurrence advances its eight columns as two alternating 4-column recurrences (k_bwd_halves, N = 512 only).  Same
-    window, same tolerances, ragged batch (B = 60: the last group has a padded half), ring reuse across launches."""
+@pytest.mark.parametrize("fused,B", [(True, 60), (False, 60), (True, 59)])
+def test_backward_two_half_form_matches_oracle(oracle32, monkeypatch, fused, B):
+    """LSTM_HIP_BWD_HALVES=1 (read per handle at create): each workgroup of the backward recurrence advances its eight
+    columns as two alternating 4-column recurrences (k_bwd_halves, N = 512 only), with the gradient sums dW, db, dWhy
+    inside the kernel (fused) or left to the separate passes.  Same window, same tolerances, ragged batch (the last group
+    has a padded half, B = 59 a padded column inside a half), ring reuse across launches."""
     import lstm_hip
     from oracle_lib import Oracle
-    N, S, B = 512, 11, 60
+    N, S = 512, 11
     monkeypatch.setenv("LSTM_HIP_BWD_HALVES", "1")
-    L = lstm_hip.Lstm(N, S, B, flags=lstm_hip.NO_FUSED_GRADS)
+    L = lstm_hip.Lstm(N, S, B, flags=0 if fused else lstm_hip.NO_FUSED_GRADS)
     monkeypatch.delenv("LSTM_HIP_BWD_HALVES")
     orc = Oracle("f32_omp")
     for rep in range(4):

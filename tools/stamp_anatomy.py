@@ -85,6 +85,23 @@ if os.environ.get("LSTM_HIP_BWD_HALVES", "0") != "0":   # two-half backward form
             ("dg_t published -> next count complete (on the chain)", s[t - 1, 1] - s[t, 3]),
             ("   dg_t published -> wave 3's half-A fragments complete", s[t - 1, 9] - s[t, 3]),
         ])
+    s = st[2]
+    t = np.arange(S - 6, 3, -1)
+    show("wave 11 (output layer ahead of the chain), workgroup 0", [
+        ("period (loop top to loop top)", s[t - 1, 12] - s[t, 12]),
+        ("wait for the slot (step t+4 consumed)", s[t, 13] - s[t, 12]),
+        ("tile to LDS (needs last step's loads) + next request", s[t, 14] - s[t, 13]),
+        ("128 LDS reads + 256 packed multiply-adds", s[t, 15] - s[t, 14]),
+        ("fold + dhy out + signal -> next loop top", s[t - 1, 12] - s[t, 15]),
+        ("lead over the elementwise wave: its step-t start minus this wave's", s[t, 0] - s[t, 12]),
+    ])
+    tt = np.arange(S - 1, 0, -1)
+    print("wave 8 prologue at t=S-1: slots 5, 6, 0, 1, 2, 3 relative to slot 5:", (s[S - 1, [5, 6, 0, 1, 2, 3]] - s[S - 1, 5]).astype(np.int64),
+          " wave 3 first slot 8 relative to it:", int(s[S - 2, 8] - s[S - 1, 5]))
+    print("wave 8 publish stamps (slot 3), step by step, relative to the first; then wave 3 slot 8")
+    print(np.array2string((s[tt, 3] - s[S - 1, 3]).astype(np.int64), max_line_width=150))
+    tt = np.arange(S - 2, 0, -1)
+    print(np.array2string((s[tt, 8] - s[S - 1, 3]).astype(np.int64), max_line_width=150))
     sys.exit(0)
 
 df = os.environ.get("LSTM_HIP_BWD_HANDOFF", "c")[0] == "f"
