@@ -66,7 +66,7 @@ if os.environ.get("LSTM_HIP_FWD_HALVES", "1") != "0":   # two-half form: wave 3 
             ("half A published -> wave 3's next half-A poll complete", s[t + 1, 9] - s[t, 3]),
         ])
 
-if os.environ.get("LSTM_HIP_BWD_HALVES", "0") != "0":   # two-half backward form (needs STAMP_FLAGS=64: unfused sums)
+if os.environ.get("LSTM_HIP_BWD_HALVES", "7") != "0":   # two-half backward form (the default)
     for wg in (2, 3):
         s = st[wg]
         t = np.arange(S - 5, 3, -1)
