@@ -12,7 +12,7 @@ import json
 import sys
 from collections import defaultdict
 
-NAMES = {"k_bwd_persistent": "bwd_persistent", "k_fwd_persistent": "fwd_persistent", "k_gemm<false, true": "gemm_dU",
+NAMES = {"k_bwd_persistent": "bwd_persistent", "k_bwd_halves": "bwd_persistent", "k_fwd_persistent": "fwd_persistent", "k_gemm<false, true": "gemm_dU",
          "k_gemm<false, false": "gemm_Y", "k_adagrad": "adagrad", "k_softmax_loss_dy": "softmax_loss_dy"}
 
 
