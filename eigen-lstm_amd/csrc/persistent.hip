@@ -1353,6 +1353,19 @@ template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_product(co
                 const int off = slot_off(t + 1, hf);
                 if (use_hint) { // one request per wave until the last-stored piece of each producer of this K-slice is in
                     const int hoff = (int)(((size_t)((t + 1 + ring_base) & (HX_RING - 1)) * B * G4 + hint_ofs[hf]) * sizeof(float));
+                    if (cfg & 4) {
+                        // two hint requests in flight, half a round trip apart: the poll's granularity is part of the hop
+                        float4 ha = {0.f, 0.f, 0.f, 0.f}, hb = ha;
+                        if (l < Kw / 16) ha = ld_sc1(rDG, hoff);
+                        for (int i = 0; i < (cfg >> 8); i++) __builtin_amdgcn_s_sleep(1);
+                        for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                            if (l < Kw / 16) hb = ld_sc1(rDG, hoff);
+                            if (__all(hx_ready(ha))) break;
+                            if (l < Kw / 16) ha = ld_sc1(rDG, hoff);
+                            if (__all(hx_ready(hb))) break;
+                            if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        }
+                    } else
                     for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
                         float4 hv = {0.f, 0.f, 0.f, 0.f};
                         if (l < Kw / 16) hv = ld_sc1(rDG, hoff);
