@@ -1272,7 +1272,10 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, s_do
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;                                                                    \
     const int NBK = gridDim.x, NG = gridDim.y;                                                                                  \
     const int lin_ = blockIdx.x + NBK * blockIdx.y;                                                                             \
-    const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;                    \
+    /* cfg bit 16 (tests): keep the dispatch-order mapping, which spreads every column group over all XCDs -- the placement  */ \
+    /* the XCD-local publish must detect and decline                                                                         */ \
+    const bool remap_ = GROUP_REMAP && !(cfg & 16);                                                                             \
+    const int kb = remap_ ? lin_ / NG : (int)blockIdx.x, g = remap_ ? lin_ % NG : (int)blockIdx.y;                              \
     const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DGx, (size_t)HX_RING * G4 * B * sizeof(float));                                \
     unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;                                                               \
     /* a wave that gives up: the abort word ends the launch everywhere, the LDS word releases this workgroup's other waves */   \
@@ -1326,6 +1329,7 @@ template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_product(co
     // hint: lane i < Kw/16 looks at producer workgroup i of this wave's K-slice (one gate, Kw consecutive units): the
     // 16 bytes its elementwise wave stores from its last lane (column 3 of the half, units 12-15)
     const bool use_hint = (cfg & 1) != 0, spec_a = (cfg & 2) == 0;
+    const int hint_sleep = (cfg >> 8) ? (cfg >> 8) - 1 : 1; // pauses of 64 cycles between hint polls (tuning; default 1)
     int hint_ofs[2];
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
@@ -1353,25 +1357,13 @@ template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_product(co
                 const int off = slot_off(t + 1, hf);
                 if (use_hint) { // one request per wave until the last-stored piece of each producer of this K-slice is in
                     const int hoff = (int)(((size_t)((t + 1 + ring_base) & (HX_RING - 1)) * B * G4 + hint_ofs[hf]) * sizeof(float));
-                    if (cfg & 4) {
-                        // two hint requests in flight, half a round trip apart: the poll's granularity is part of the hop
-                        float4 ha = {0.f, 0.f, 0.f, 0.f}, hb = ha;
-                        if (l < Kw / 16) ha = ld_sc1(rDG, hoff);
-                        for (int i = 0; i < (cfg >> 8); i++) __builtin_amdgcn_s_sleep(1);
-                        for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
-                            if (l < Kw / 16) hb = ld_sc1(rDG, hoff);
-                            if (__all(hx_ready(ha))) break;
-                            if (l < Kw / 16) ha = ld_sc1(rDG, hoff);
-                            if (__all(hx_ready(hb))) break;
-                            if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                        }
-                    } else
+                    // (two hint requests in flight half a round trip apart: 360 us against 348 -- polls load the L2)
                     for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
                         float4 hv = {0.f, 0.f, 0.f, 0.f};
                         if (l < Kw / 16) hv = ld_sc1(rDG, hoff);
                         if (__all(hx_ready(hv))) break;
                         if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                        __builtin_amdgcn_s_sleep(1);
+                        for (int i = 0; i < hint_sleep; i++) __builtin_amdgcn_s_sleep(1);
                     }
                 }
                 bool ok = false;

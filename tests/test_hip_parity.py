@@ -214,6 +214,45 @@ def test_backward_two_half_form_matches_oracle(oracle32, monkeypatch, fused, B):
     L.close()
 
 
+@pytest.mark.parametrize("S", [2, 3, 5])
+def test_two_half_forms_on_very_short_windows(oracle32, S):
+    """The two-half recurrences (N = 512) run their side waves up to four steps ahead of the chain and request fragments
+    a half-step ahead: windows shorter than those look-aheads (S-1 = 1, 2, 4 timesteps) must still come out right."""
+    import lstm_hip
+    N, B = 512, 64
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=70 + S)
+    fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
+    dref = oracle32.backward(N, 256, S, B, P, xi, ti, fw)
+    got = _run_hip(lstm_hip, N, S, B, P, xi, ti, h0, c0)
+    assert abs(got["loss"] - fw["loss_bits"]) <= LOSS_TOL * (S - 1)
+    rep_ = gu.grads_report(got["grads"], dref, N)
+    assert max(rep_.values()) <= GRAD_TOL, rep_
+
+
+def test_two_half_backward_declines_xcd_local_publish_when_groups_span_xcds(oracle32, monkeypatch):
+    """Tuning bit 16 of LSTM_HIP_BWD_HALVES keeps the dispatch-order workgroup mapping in k_bwd_halves: every column group
+    then sits on all eight XCDs, the per-launch XCC check must keep the write-through publish, and the results must not
+    change (the same control as test_backward_declines_xcd_local_handoff_when_groups_span_xcds for the one-recurrence form)."""
+    import lstm_hip
+    from oracle_lib import Oracle
+    N, S, B = 512, 9, 64
+    monkeypatch.setenv("LSTM_HIP_BWD_HALVES", str(7 | (16 << 1)))
+    L = lstm_hip.Lstm(N, S, B)
+    monkeypatch.delenv("LSTM_HIP_BWD_HALVES")
+    orc = Oracle("f32_omp")
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=92)
+    fw = orc.forward(N, 256, S, B, P, xi, ti, h0, c0)
+    dref = orc.backward(N, 256, S, B, P, xi, ti, fw)
+    L.set_params(P)
+    L.set_state(0, h0, c0)
+    L.set_window(xi, ti)
+    L.forward()
+    L.backward()
+    rep_ = gu.grads_report(L.get_grads(), dref, N)
+    L.close()
+    assert max(rep_.values()) <= GRAD_TOL, rep_
+
+
 def test_dense_one_hot_inputs_entry_point(oracle32):
     """lstm_hip_set_inputs_dense = copy_inputs_to_device (OV/lstm_eigen_class_CUDA/cu_lstm.h:364-377) with the reference's
     own operands: the dense one-hot x[t], target[t] and h[0], c[0].  Same window as through the index form, bit for bit;
