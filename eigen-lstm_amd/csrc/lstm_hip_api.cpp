@@ -89,7 +89,7 @@ struct lstm_hip_ctx {
     int T = 0; // (S-1)*B columns in the time-batched matrices
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr; // the early part of the gradient all-reduce runs here, beside the dU product on `st`
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, evt0 = nullptr, evt1 = nullptr;
     bool fold_pending = false;  // the backward pass left the gradient in pieces for Adagrad to sum (single-GPU loop)
     int n_slabs_dU = 0;         // ... with this many dU slabs (0: dU is final in dP)
     bool in_loop = false;       // inside lstm_hip_train_windows: nobody reads the gradient block between backward and Adagrad
@@ -129,6 +129,9 @@ struct lstm_hip_ctx {
     int32_t *Xr = nullptr, *Tr = nullptr, *head = nullptr; // ring form kept by the device-side slide
     double *d_loss = nullptr;
     double *d_losses = nullptr;
+    double *h_losses = nullptr; // pinned twin of d_losses: the caller's (pageable) array is filled from it after the sync.
+                                // (The runtime's own staging path for a first large pageable copy cost the NEXT 20 windows
+                                // 0.4 ms of device time -- tools/train_windows_probe.py.)
     int64_t losses_cap = 0;
     uint8_t *text = nullptr;
     uint64_t text_len = 0;
@@ -531,6 +534,15 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     HIP_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&h->ev0));
     HIP_TRY(hipEventCreate(&h->ev1));
+    HIP_TRY(hipEventCreate(&h->evt0)); // train_windows' elapsed time (ev0 / ev1 belong to the per-kernel profiling)
+    HIP_TRY(hipEventCreate(&h->evt1));
+    { // first use of timed events on the stream, here rather than inside somebody's measurement
+        float ms = 0.0f;
+        HIP_TRY(hipEventRecord(h->evt0, h->st));
+        HIP_TRY(hipEventRecord(h->evt1, h->st));
+        HIP_TRY(hipEventSynchronize(h->evt1));
+        HIP_TRY(hipEventElapsedTime(&ms, h->evt0, h->evt1));
+    }
     ALLOC(h->P, h->pl.total);
     ALLOC(h->dP, h->pl.total);
     ALLOC(h->mem, h->pl.total);
@@ -638,8 +650,11 @@ int lstm_hip_destroy(lstm_hip_t *h) {
                     h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->WhyT_b, h->Why_b, h->Ht_b, h->dYt_b, h->DGt_b, h->dYb, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
+    if (h->h_losses) (void)hipHostFree(h->h_losses);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->evt0) (void)hipEventDestroy(h->evt0);
+    if (h->evt1) (void)hipEventDestroy(h->evt1);
     for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_mid})
         if (e) (void)hipEventDestroy(e);
     if (h->st2) (void)hipStreamDestroy(h->st2);
@@ -874,28 +889,25 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
     if (count < 0) return fail(LSTM_HIP_EINVAL, "train_windows: count < 0");
     if (!h->text) return fail(LSTM_HIP_ESTATE, "train_windows before set_text/set_cursors");
     if (count > h->losses_cap) {
+        const int64_t cap = count < 8192 ? 8192 : count;
         HIP_TRY(hipStreamSynchronize(h->st));
         if (h->d_losses) HIP_TRY(hipFree(h->d_losses));
+        if (h->h_losses) HIP_TRY(hipHostFree(h->h_losses));
         h->d_losses = nullptr;
-        HIP_TRY(hipMalloc((void **)&h->d_losses, sizeof(double) * count));
-        h->losses_cap = count;
+        h->h_losses = nullptr;
+        h->losses_cap = 0;
+        HIP_TRY(hipMalloc((void **)&h->d_losses, sizeof(double) * cap));
+        HIP_TRY(hipHostMalloc((void **)&h->h_losses, sizeof(double) * cap, hipHostMallocDefault));
+        h->losses_cap = cap;
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (elapsed_ms) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, h->st));
-    }
+    // the handle's own event pair (made and exercised once at create: the first timed record on a stream costs ~0.5 ms of
+    // device time, which a 20-window measurement would carry)
+    if (elapsed_ms) HIP_TRY(hipEventRecord(h->evt0, h->st));
     h->in_loop = true;
     struct LoopGuard { // leaves the loop state clean on every return path
         lstm_hip_ctx *h;
-        hipEvent_t &a, &b;
-        ~LoopGuard() {
-            h->in_loop = false;
-            if (a) (void)hipEventDestroy(a);
-            if (b) (void)hipEventDestroy(b);
-        }
-    } guard{h, e0, e1};
+        ~LoopGuard() { h->in_loop = false; }
+    } guard{h};
     for (int64_t i = 0; i < count; i++) {
         RUN(K_SLIDE, slide_window(h->text, h->text_len, h->pos, h->Xr, h->Tr, h->head, h->xi, h->ti, h->H, h->C,
                                   h->cfg.S, h->cfg.B, h->cfg.N, h->stride, h->carry_col, h->st));
@@ -909,13 +921,14 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
         if ((rc = do_adagrad(h, learning_rate))) return rc;
     }
     if (elapsed_ms) {
-        HIP_TRY(hipEventRecord(e1, h->st));
-        HIP_TRY(hipEventSynchronize(e1));
-        HIP_TRY(hipEventElapsedTime(elapsed_ms, e0, e1));
+        HIP_TRY(hipEventRecord(h->evt1, h->st));
+        HIP_TRY(hipEventSynchronize(h->evt1));
+        HIP_TRY(hipEventElapsedTime(elapsed_ms, h->evt0, h->evt1));
     }
     if (losses && count > 0)
-        HIP_TRY(hipMemcpyAsync(losses, h->d_losses, sizeof(double) * count, hipMemcpyDeviceToHost, h->st));
+        HIP_TRY(hipMemcpyAsync(h->h_losses, h->d_losses, sizeof(double) * count, hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
+    if (losses && count > 0) std::memcpy(losses, h->h_losses, sizeof(double) * count);
     return check_abort(h);
 }
 
