@@ -47,6 +47,39 @@ const char *const kKernelNames[K_COUNT] = {
     "pack_U", "fwd_step", "gemm_Y", "softmax_loss_dy", "loss_reduce", "gemm_DHy", "bwd_step", "gemm_dWhy", "gemm_dU",
     "dW_db", "loss_dby", "adagrad", "slide", "allreduce", "fwd_persistent", "bwd_persistent"};
 
+// ---- rocBLAS for the two plain time-batched fp32 products (Y = Why*H and dU = DG*H^T), loaded with dlopen -----------------
+// These are library GEMMs in the plainest sense (column-major, no epilogue), and rocBLAS's tuned kernels run them at
+// 138 TFLOP/s / 17.8 us against 113 TFLOP/s / 32 us for k_gemm (tools/probes/rocblas_dU_probe.cpp).  Atomics are
+// disallowed on the handle, which keeps its reductions deterministic (checked bit for bit by the same probe).  Without
+// the library, or with LSTM_HIP_GEMM=native, k_gemm serves them as before.
+struct Rocblas {
+    void *lib = nullptr;
+    int (*create)(void **) = nullptr;
+    int (*destroy)(void *) = nullptr;
+    int (*set_stream)(void *, hipStream_t) = nullptr;
+    int (*set_atomics)(void *, int) = nullptr;
+    int (*sgemm)(void *, int, int, int, int, int, const float *, const float *, int, const float *, int, const float *, float *,
+                 int) = nullptr;
+};
+Rocblas g_blas;
+bool load_rocblas() {
+    if (g_blas.lib) return true;
+    void *lib = dlopen("librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return false;
+    Rocblas b;
+    b.create = (decltype(b.create))dlsym(lib, "rocblas_create_handle");
+    b.destroy = (decltype(b.destroy))dlsym(lib, "rocblas_destroy_handle");
+    b.set_stream = (decltype(b.set_stream))dlsym(lib, "rocblas_set_stream");
+    b.set_atomics = (decltype(b.set_atomics))dlsym(lib, "rocblas_set_atomics_mode");
+    b.sgemm = (decltype(b.sgemm))dlsym(lib, "rocblas_sgemm");
+    if (!b.create || !b.destroy || !b.set_stream || !b.set_atomics || !b.sgemm) return false;
+    b.lib = lib;
+    g_blas = b;
+    return true;
+}
+constexpr int ROCBLAS_OP_N = 111, ROCBLAS_OP_T = 112; // rocblas_operation_none / _transpose
+
 // ---- RCCL, loaded on first use so single-GPU users never touch it --------------------------
 struct UniqueId {
     char internal[LSTM_HIP_UNIQUE_ID_BYTES];
@@ -111,6 +144,7 @@ struct lstm_hip_ctx {
     float4 *Ufwd = nullptr, *Ubwd = nullptr;
     float4 *Ubwd4 = nullptr; // weight image of the 4x4x1 backward form (kernels.hip, k_pack_U), when bwd_uses_m4
     float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel (fwd_uses_8col_form) or, fwd_cols4, of the two-half one
+    void *blas = nullptr;    // rocBLAS handle on `st` (null: k_gemm serves the time-batched products)
     bool side_stream = true; // LSTM_HIP_NO_SIDE_STREAM=1 (per handle): keep the whole window on one stream
     int bwd_halves = 0;      // 1: backward recurrence likewise (k_bwd_halves; LSTM_HIP_BWD_HALVES=1, unfused gradient sums)
     int fwd_cols4 = 0;       // 1: forward recurrence as two alternating 4-column halves per workgroup (k_fwd_persistent6)
@@ -292,6 +326,13 @@ int do_forward(lstm_hip_ctx *h) {
         RUN(K_GEMM_Y, gemm_bf16(256, h->T, N, h->WhyT_b, N, h->Hb + (size_t)N * B, N, h->Y + (size_t)256 * B, 256, 1, nullptr,
                                 h->st));
     } else
+    if (h->blas) {
+        const float one = 1.0f, zero = 0.0f;
+        int rc = 0;
+        RUN(K_GEMM_Y, rc = g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_N, 256, h->T, N, &one, h->P + h->pl.Why, 256,
+                                        h->H + (size_t)N * B, N, &zero, h->Y + (size_t)256 * B, 256));
+        if (rc != 0) return fail(LSTM_HIP_EHIP, "rocblas_sgemm (Y): status %d", rc);
+    } else
     RUN(K_GEMM_Y, gemm(false, false, 256, h->T, N, h->P + h->pl.Why, 256, h->H + (size_t)N * B, N,
                        h->Y + (size_t)256 * B, 256, 1, nullptr, h->st));
     RUN(K_SOFTMAX, softmax_loss_dy(h->Y + (size_t)256 * B, h->Pr + (size_t)256 * B, h->P + h->pl.by, h->ti + B,
@@ -416,6 +457,13 @@ int do_backward(lstm_hip_ctx *h) {
         RUN(K_GEMM_DU, (transpose_pack_bf16(h->DG + (size_t)G4 * B, T, G4, G4, h->DGt_b, h->Tpad, h->st),
                         gemm_bf16(G4, N, h->Tpad, h->DGt_b, h->Tpad, h->Ht_b, h->SBpad, h->dP + h->pl.U, G4, h->splits_dU,
                                   h->slabs_dU, h->st)));
+    } else if (h->blas) {
+        const float one = 1.0f, zero = 0.0f;
+        int rc = 0;
+        h->n_slabs_dU = 0; // straight into the gradient block
+        RUN(K_GEMM_DU, rc = g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_T, G4, N, T, &one, h->DG + (size_t)G4 * B, G4, h->H, N,
+                                         &zero, h->dP + h->pl.U, G4));
+        if (rc != 0) return fail(LSTM_HIP_EHIP, "rocblas_sgemm (dU): status %d", rc);
     } else if (defer_fold && h->splits_dU > 1)
         RUN(K_GEMM_DU, h->n_slabs_dU = gemm_slabs(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->slabs_dU,
                                                    h->splits_dU, h->st));
@@ -633,6 +681,24 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
     if (h->persistent && (cfg->flags & LSTM_HIP_DEBUG_STAMPS) && cfg->N == 512 && h->Hx && h->Ubwd4) ALLOC(h->stamps, 4 * S * 16);
+    const char *gsel = getenv("LSTM_HIP_GEMM"); // "native": k_gemm (read per handle)
+    if (!h->bf16 && !(gsel && gsel[0] == 'n') && load_rocblas()) {
+        if (g_blas.create(&h->blas) != 0) h->blas = nullptr;
+        if (h->blas && (g_blas.set_stream(h->blas, h->st) != 0 || g_blas.set_atomics(h->blas, 0 /* not allowed */) != 0)) {
+            (void)g_blas.destroy(h->blas);
+            h->blas = nullptr;
+        }
+        if (h->blas) { // first calls load and pick the kernels (tens of ms): here, not inside somebody's first window
+            const float one = 1.0f, zero = 0.0f;
+            (void)g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_N, 256, h->T, (int)N, &one, h->P + h->pl.Why, 256, h->H + N * B,
+                               (int)N, &zero, h->Y + (size_t)256 * B, 256);
+            (void)g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_T, (int)G4, (int)N, h->T, &one, h->DG + G4 * B, (int)G4, h->H, (int)N,
+                               &zero, h->dP + h->pl.U, (int)G4);
+            HIP_TRY(hipStreamSynchronize(h->st));
+            HIP_TRY(hipMemsetAsync(h->dP, 0, sizeof(float) * h->pl.total, h->st));
+            HIP_TRY(hipMemsetAsync(h->Y, 0, sizeof(float) * 256 * S * B, h->st));
+        }
+    }
     HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
@@ -651,6 +717,7 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->h_losses) (void)hipHostFree(h->h_losses);
+    if (h->blas) (void)g_blas.destroy(h->blas);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->evt0) (void)hipEventDestroy(h->evt0);

@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 NAMES = {"k_bwd_persistent": "bwd_persistent", "k_bwd_halves": "bwd_persistent", "k_fwd_persistent": "fwd_persistent", "k_gemm<false, true": "gemm_dU",
-         "k_gemm<false, false": "gemm_Y"}
+         "k_gemm<false, false": "gemm_Y", "Cijk_Ailk_Bljk": "gemm_Y", "Cijk_Ailk_Bjlk": "gemm_dU"}
 OUT = sys.argv[2] if len(sys.argv) > 2 else "profiles/r2_mfma_util.json"
 acc = defaultdict(lambda: defaultdict(list))
 with open(sys.argv[1]) as f:

@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 NAMES = {"k_bwd_persistent": "bwd_persistent", "k_bwd_halves": "bwd_persistent", "k_fwd_persistent": "fwd_persistent", "k_gemm<false, true": "gemm_dU",
-         "k_gemm<false, false": "gemm_Y", "k_adagrad": "adagrad", "k_softmax_loss_dy": "softmax_loss_dy"}
+         "k_gemm<false, false": "gemm_Y", "Cijk_Ailk_Bljk": "gemm_Y", "Cijk_Ailk_Bjlk": "gemm_dU", "k_adagrad": "adagrad", "k_softmax_loss_dy": "softmax_loss_dy"}
 
 
 OUT = sys.argv[3] if len(sys.argv) > 3 else "profiles/r2_pmc_traffic.json"
