@@ -145,6 +145,7 @@ struct lstm_hip_ctx {
     float4 *Ubwd4 = nullptr; // weight image of the 4x4x1 backward form (kernels.hip, k_pack_U), when bwd_uses_m4
     float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel (fwd_uses_8col_form) or, fwd_cols4, of the two-half one
     void *blas = nullptr;    // rocBLAS handle on `st` (null: k_gemm serves the time-batched products)
+    bool blas_Y = false, blas_dU = false; // which of the two products go through it: whichever was faster at create
     bool side_stream = true; // LSTM_HIP_NO_SIDE_STREAM=1 (per handle): keep the whole window on one stream
     int bwd_halves = 0;      // 1: backward recurrence likewise (k_bwd_halves; LSTM_HIP_BWD_HALVES=1, unfused gradient sums)
     int fwd_cols4 = 0;       // 1: forward recurrence as two alternating 4-column halves per workgroup (k_fwd_persistent6)
@@ -326,7 +327,7 @@ int do_forward(lstm_hip_ctx *h) {
         RUN(K_GEMM_Y, gemm_bf16(256, h->T, N, h->WhyT_b, N, h->Hb + (size_t)N * B, N, h->Y + (size_t)256 * B, 256, 1, nullptr,
                                 h->st));
     } else
-    if (h->blas) {
+    if (h->blas_Y) {
         const float one = 1.0f, zero = 0.0f;
         int rc = 0;
         RUN(K_GEMM_Y, rc = g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_N, 256, h->T, N, &one, h->P + h->pl.Why, 256,
@@ -457,7 +458,7 @@ int do_backward(lstm_hip_ctx *h) {
         RUN(K_GEMM_DU, (transpose_pack_bf16(h->DG + (size_t)G4 * B, T, G4, G4, h->DGt_b, h->Tpad, h->st),
                         gemm_bf16(G4, N, h->Tpad, h->DGt_b, h->Tpad, h->Ht_b, h->SBpad, h->dP + h->pl.U, G4, h->splits_dU,
                                   h->slabs_dU, h->st)));
-    } else if (h->blas) {
+    } else if (h->blas_dU) {
         const float one = 1.0f, zero = 0.0f;
         int rc = 0;
         h->n_slabs_dU = 0; // straight into the gradient block
@@ -688,12 +689,53 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
             (void)g_blas.destroy(h->blas);
             h->blas = nullptr;
         }
-        if (h->blas) { // first calls load and pick the kernels (tens of ms): here, not inside somebody's first window
+        if (h->blas) {
+            // First calls load and pick the kernels (tens of ms): here, not inside somebody's first window.  Then each
+            // product goes to whichever of the two implementations is faster for this shape on this device (rocBLAS wins
+            // both at the headline shape; k_gemm keeps e.g. Y at hidden 1024 with 12 672 columns, 120 against 255 us).
             const float one = 1.0f, zero = 0.0f;
-            (void)g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_N, 256, h->T, (int)N, &one, h->P + h->pl.Why, 256, h->H + N * B,
-                               (int)N, &zero, h->Y + (size_t)256 * B, 256);
-            (void)g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_T, (int)G4, (int)N, h->T, &one, h->DG + G4 * B, (int)G4, h->H, (int)N,
-                               &zero, h->dP + h->pl.U, (int)G4);
+            auto blas_Y = [&]() {
+                (void)g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_N, 256, h->T, (int)N, &one, h->P + h->pl.Why, 256, h->H + N * B,
+                                   (int)N, &zero, h->Y + (size_t)256 * B, 256);
+            };
+            auto own_Y = [&]() {
+                gemm(false, false, 256, h->T, (int)N, h->P + h->pl.Why, 256, h->H + N * B, (int)N, h->Y + (size_t)256 * B, 256, 1,
+                     nullptr, h->st);
+            };
+            auto blas_dU = [&]() {
+                (void)g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_T, (int)G4, (int)N, h->T, &one, h->DG + G4 * B, (int)G4, h->H,
+                                   (int)N, &zero, h->dP + h->pl.U, (int)G4);
+            };
+            auto own_dU = [&]() {
+                if (h->splits_dU > 1)
+                    (void)gemm_slabs(false, true, (int)G4, (int)N, h->T, h->DG + G4 * B, (int)G4, h->H, (int)N, h->slabs_dU,
+                                     h->splits_dU, h->st);
+                else
+                    gemm(false, true, (int)G4, (int)N, h->T, h->DG + G4 * B, (int)G4, h->H, (int)N, h->dP + h->pl.U, (int)G4, 1,
+                         nullptr, h->st);
+            };
+            auto best_ms = [&](auto &&fn, float *out) -> int { // best of three, after two warm-up calls
+                fn();
+                fn();
+                float best = 1e30f;
+                for (int i = 0; i < 3; i++) {
+                    float ms = 0.0f;
+                    HIP_TRY(hipEventRecord(h->evt0, h->st));
+                    fn();
+                    HIP_TRY(hipEventRecord(h->evt1, h->st));
+                    HIP_TRY(hipEventSynchronize(h->evt1));
+                    HIP_TRY(hipEventElapsedTime(&ms, h->evt0, h->evt1));
+                    best = ms < best ? ms : best;
+                }
+                *out = best;
+                return 0;
+            };
+            float tb = 0.f, to = 0.f;
+            int rc_ = 0;
+            if ((rc_ = best_ms(blas_Y, &tb)) || (rc_ = best_ms(own_Y, &to))) return rc_;
+            h->blas_Y = tb < 0.9f * to; // a clear win only: the choice should not flip from run to run
+            if ((rc_ = best_ms(blas_dU, &tb)) || (rc_ = best_ms(own_dU, &to))) return rc_;
+            h->blas_dU = tb < 0.9f * to;
             HIP_TRY(hipStreamSynchronize(h->st));
             HIP_TRY(hipMemsetAsync(h->dP, 0, sizeof(float) * h->pl.total, h->st));
             HIP_TRY(hipMemsetAsync(h->Y, 0, sizeof(float) * 256 * S * B, h->st));
