@@ -792,18 +792,21 @@ void pack_bf16(const float *src, size_t n, unsigned short *dst, hipStream_t st) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// softmax_loss_dy: one wave per output column (M = 256 = 64 lanes x float4).
+// softmax_loss_dy: one wave per output column (M = 256 = 64 lanes x float4), two columns per wave, four waves per workgroup;
+// the workgroup leaves ONE row of dby partial sums (its eight columns in order).  (Eight columns per wave: 13 us -- too few
+// waves in flight; two per wave with a partial row per wave: 8.8 us but the fold over 4x the rows cost 8 us more.)
 //   probs = exp(y + by) / sum  (no max shift)     R/lstm.cc:195-201
 //   surprisal = -log2(probs[target])              R/lstm.cc:204
 //   dy = probs - target                           R/lstm.cc:225
 // ------------------------------------------------------------------------------------------------
-constexpr int SM_COLS_PER_WAVE = 8;
+constexpr int SM_COLS_PER_WAVE = 2;
 __global__ __launch_bounds__(256) void k_softmax_loss_dy(float *__restrict__ Y, float *__restrict__ P,
                                                          const float *__restrict__ by, const int32_t *__restrict__ ti,
                                                          float *__restrict__ colloss, float *__restrict__ dby_part,
                                                          int col0, int T) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int gw = col0 / SM_COLS_PER_WAVE + blockIdx.x * 4 + w; // global wave index: columns 8*gw .. 8*gw+7
+    __shared__ float4 part[4][64];
+    const int gw = col0 / SM_COLS_PER_WAVE + blockIdx.x * 4 + w; // global wave index: columns 2*gw, 2*gw+1
     const float4 b4 = reinterpret_cast<const float4 *>(by)[l];
     float4 dsum = {0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < SM_COLS_PER_WAVE; q++) {
@@ -841,11 +844,23 @@ __global__ __launch_bounds__(256) void k_softmax_loss_dy(float *__restrict__ Y, 
         dsum.z += d.z;
         dsum.w += d.w;
     }
-    reinterpret_cast<float4 *>(dby_part + (size_t)gw * 256)[l] = dsum;
+    part[w][l] = dsum;
+    __syncthreads();
+    if (w == 0) {
+        float4 s = part[0][l];
+#pragma unroll
+        for (int i = 1; i < 4; i++) {
+            s.x += part[i][l].x;
+            s.y += part[i][l].y;
+            s.z += part[i][l].z;
+            s.w += part[i][l].w;
+        }
+        reinterpret_cast<float4 *>(dby_part + (size_t)(col0 / (4 * SM_COLS_PER_WAVE) + blockIdx.x) * 256)[l] = s;
+    }
 }
 // columns [col0, col1) of a T-column problem; col0 must be a multiple of 8.  dby_part needs
 // softmax_parts(T) rows of 256 floats; rows of waves past col1 are written as zeros.
-int softmax_parts(int T) { return ((T + SM_COLS_PER_WAVE - 1) / SM_COLS_PER_WAVE + 3) / 4 * 4 + 4; }
+int softmax_parts(int T) { return (T + 4 * SM_COLS_PER_WAVE - 1) / (4 * SM_COLS_PER_WAVE) + 4; } // one row per workgroup
 void softmax_loss_dy(float *Y, float *P, const float *by, const int32_t *ti, float *colloss, float *dby_part, int col0,
                      int col1, hipStream_t st) {
     const int waves = (col1 - col0 + SM_COLS_PER_WAVE - 1) / SM_COLS_PER_WAVE;
