@@ -126,6 +126,7 @@ struct lstm_hip_ctx {
     bool fold_pending = false;  // the backward pass left the gradient in pieces for Adagrad to sum (single-GPU loop)
     int n_slabs_dU = 0;         // ... with this many dU slabs (0: dU is final in dP)
     bool in_loop = false;       // inside lstm_hip_train_windows: nobody reads the gradient block between backward and Adagrad
+    size_t dU_reduced = 0;      // ... and so are this many leading floats of the dU range (its first column half)
     bool early_reduced = false; // [dW] and [db | dWhy | dby] are already being all-reduced on st2 (ev_join marks the end)
     float *slabs_dU = nullptr; // split-K slabs of dU
     bool bf16 = false;         // LSTM_HIP_BF16_RECURRENCE
@@ -449,8 +450,29 @@ int do_backward(lstm_hip_ctx *h) {
         }
         if (rc != 0)
             return fail(LSTM_HIP_ERCCL, "ncclAllReduce (early ranges): %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+        // With the dU product in two column halves (rocBLAS path), the first half's all-reduce also goes on st2, behind the
+        // early ranges and beside the second half's product; only the second half is left for `st`.
+        h->dU_reduced = 0;
+        if (h->blas_dU && !h->bf16) {
+            const float one = 1.0f, zero = 0.0f;
+            const int n1 = N / 2;
+            int brc = g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_T, G4, n1, T, &one, h->DG + (size_t)G4 * B, G4, h->H, N, &zero,
+                                   h->dP + h->pl.U, G4);
+            if (brc != 0) return fail(LSTM_HIP_EHIP, "rocblas_sgemm (dU, first half): status %d", brc);
+            HIP_TRY(hipEventRecord(h->ev_mid, h->st));
+            brc = g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_T, G4, N - n1, T, &one, h->DG + (size_t)G4 * B, G4, h->H + n1, N,
+                               &zero, h->dP + h->pl.U + (size_t)G4 * n1, G4);
+            if (brc != 0) return fail(LSTM_HIP_EHIP, "rocblas_sgemm (dU, second half): status %d", brc);
+            HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_mid, 0));
+            h->dU_reduced = (size_t)G4 * n1;
+            rc = g_rccl.AllReduce(h->dP + h->pl.U, h->dP + h->pl.U, h->dU_reduced, 7, 0, h->comm, h->st2);
+            if (rc != 0)
+                return fail(LSTM_HIP_ERCCL, "ncclAllReduce (dU, first half): %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+            h->n_slabs_dU = 0;
+        }
         HIP_TRY(hipEventRecord(h->ev_join, h->st2));
         h->early_reduced = true;
+        if (h->dU_reduced) return 0; // the product is done
     }
     // dU = DG * H[0..S-2]^T            R/lstm.cc:250
     if (h->bf16) { // dg_t pairs with h_{t-1}: column (t-1)*B+b of both images
@@ -487,7 +509,10 @@ int do_allreduce(lstm_hip_ctx *h) {
     if (h->early_reduced) {
         h->early_reduced = false;
         HIP_TRY(hipStreamWaitEvent(h->st, h->ev_join, 0));
-        RUN(K_ALLREDUCE, rc = g_rccl.AllReduce(h->dP + h->pl.U, h->dP + h->pl.U, h->pl.b - h->pl.U, 7, 0, h->comm, h->st));
+        const size_t done = h->dU_reduced;
+        h->dU_reduced = 0;
+        RUN(K_ALLREDUCE, rc = g_rccl.AllReduce(h->dP + h->pl.U + done, h->dP + h->pl.U + done, h->pl.b - h->pl.U - done, 7, 0, h->comm,
+                                               h->st));
     } else
     RUN(K_ALLREDUCE, rc = g_rccl.AllReduce(h->dP, h->dP, h->pl.total, /*ncclFloat*/ 7, /*ncclSum*/ 0, h->comm, h->st));
     if (rc != 0)

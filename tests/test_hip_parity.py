@@ -645,6 +645,34 @@ def test_rccl_path_with_a_single_rank_communicator():
     assert np.array_equal(l0, l1) and np.array_equal(p0, p1)
 
 
+def test_rccl_path_at_the_headline_shape_splits_the_dU_all_reduce():
+    """With a communicator the dU product runs as two column halves (rocBLAS) and the first half's all-reduce goes out on
+    the second stream beside the second half's product.  1-rank communicator, headline shape: the trajectory must follow
+    the run without a communicator (not bit for bit: the half-size products may sum in another order)."""
+    import lstm_hip
+    N, S, B, windows = 512, 100, 64, 12
+    text = _synthetic_text(20000, seed=11)
+
+    def run(with_comm):
+        L = lstm_hip.Lstm(N, S, B)
+        L.set_params(lstm_hip.init_params(lstm_hip.MT19937Normal(5), N))
+        L.set_text(text)
+        L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
+        if with_comm:
+            L.comm_init(lstm_hip.comm_unique_id(), 1, 0)
+            L.set_global_batch(B)
+        losses = L.train_windows(windows, 0.01)
+        P = L.get_params()
+        L.close()
+        return losses, P
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert np.all(np.isfinite(l1))
+    assert np.max(np.abs(l1 - l0)) <= 1e-3 * np.max(np.abs(l0))
+    assert np.max(np.abs(p1 - p0)) <= 1e-4
+
+
 def test_stride_variant_matches_oracle(oracle32):
     """Window stride > 1 (OV/lstm_eigen_class_batch/lstm_segment.cc:110,130,183-187): every stream advances
     `stride` bytes per window and the carry comes from column stride-1.  Lock-step against the oracle's slide
