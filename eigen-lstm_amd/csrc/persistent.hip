@@ -1453,7 +1453,11 @@ template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_elementwis
         cv = C[((size_t)tu * B + ecolc) * N + j], cp = C[((size_t)(tu - 1) * B + ecolc) * N + j];
     };
     fetch(S - 1);
-    for (int t = S - 1; t >= 1; t--) {
+    float dhy = 0.0f;
+    const bool alive = lds_wait(s_ol, 1u);
+    if (alive) dhy = dhyb[((S - 1) & 3) * 128 + (4 * hf + cc) * 16 + jj];
+    else give_up();
+    for (int t = S - 1; t >= 1 && alive; t--) {
         HSTAMP(8, 0)
         float dhn = 0.0f;
         if (t < S - 1) {
@@ -1474,12 +1478,7 @@ template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_elementwis
             }
             dhn = (sm.x + sm.y) + (sm.z + sm.w);
         }
-        // the output-layer term of this step: wave 11 runs ahead of the chain, so this does not wait in practice
-        if (!lds_wait(s_ol, (unsigned)(S - t))) {
-            give_up();
-            break;
-        }
-        const float dhy = dhyb[(t & 3) * 128 + (4 * hf + cc) * 16 + jj];
+        // (dhy: the output-layer term of this step, picked up from wave 11's buffer a step ago, off the chain)
         if (XCD_LOCAL && t == S - 2) { // every workgroup of the group has published dg_{S-1}, its XCC id before it
             unsigned mine = 0;
             bool same = true;
@@ -1544,7 +1543,15 @@ template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_elementwis
             *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
         }
         HSTAMP(8, 4)
-        if (t >= 2) fetch(t - 1);
+        if (t >= 2) {
+            fetch(t - 1);
+            // wave 11 runs up to four steps ahead of the chain, so this does not wait in practice
+            if (!lds_wait(s_ol, (unsigned)(S - (t - 1)))) {
+                give_up();
+                break;
+            }
+            dhy = dhyb[((t - 1) & 3) * 128 + (4 * hf + cc) * 16 + jj];
+        }
         if (FUSE) {
             if (ecol < B) { // db += dg, R/lstm.cc:252
                 dbacc[0] += d_i;
