@@ -701,7 +701,11 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
     static_assert(Kw == 64, "one 16-byte load per lane covers a wave's K-slice of a half");
     __shared__ __attribute__((aligned(16))) float red[2][2][8 * 4 * RS]; // [half][step parity][wave][column][4*unit + gate]
     __shared__ int s_abort;
-    __shared__ unsigned s_done[2]; // per half: partial-sum images written so far, summed over the product waves (8 per step)
+    // Per half and STEP PARITY: partial-sum images written so far, summed over the product waves (8 per step of that parity).
+    // One count per half would not do: a product wave whose K-slice is fed by other workgroups can be a step ahead of a
+    // wave of its own workgroup that is still waiting for a slow load (two steps ahead it cannot be: that needs this
+    // workgroup's h of the step in between), and its early count would stand in for the late wave's missing one.
+    __shared__ unsigned s_done[2][2];
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int NB3 = gridDim.x, NG = gridDim.y;
     const int lin_ = blockIdx.x + NB3 * blockIdx.y;
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
     unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
     if (tid == 0) {
         s_abort = 0;
-        s_done[0] = s_done[1] = 0;
+        s_done[0][0] = s_done[0][1] = s_done[1][0] = s_done[1][1] = 0;
         if (XCD_LOCAL) {
             __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -794,7 +798,7 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
 #pragma unroll
                 for (int r = 0; r < 4; r++) rp[(w * 4 + r) * RS + l] = (c0[r] + c1[r]) + (c2[r] + c3[r]);
                 asm volatile("" ::: "memory");
-                if (l == 0) __hip_atomic_fetch_add(&s_done[hf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (l == 0) __hip_atomic_fetch_add(&s_done[hf][t & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (hf == 0) { FSTAMP(3, 11) } else { FSTAMP(3, 7) }
             }
         }
@@ -825,7 +829,8 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
             {   // all eight partial-sum images of this half and step are in LDS
                 bool in = false;
                 for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
-                    in = __hip_atomic_load(&s_done[hf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 8u * (unsigned)t;
+                    // steps 1..t of the parity of t: (t + 1) / 2 of them
+                    in = __hip_atomic_load(&s_done[hf][t & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 8u * (unsigned)((t + 1) / 2);
                     if (in || __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -1247,14 +1252,18 @@ struct BwdhArgs {
     int ring_base, S, B, cfg;
     unsigned long long *stamps;
 };
-constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, s_done[2], s_stage[2], s_dy, s_ol, s_tab
+constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -, s_stage[2], s_dy, s_ol, s_tab, s_done[2][2]
 #define BWDH_COMMON(p)                                                                                                          \
     constexpr int N = 512, G4 = 4 * N, Kw = N / 2, NL = Kw / 64; /* NL 16-byte loads per lane, half and step */                 \
     constexpr int WS = 256;                                      /* partial-sum image: [wave][column*16 + unit][Y] */           \
     extern __shared__ __attribute__((aligned(16))) float lds[];                                                                 \
     unsigned *sync_ = reinterpret_cast<unsigned *>(lds);                                                                        \
     int *s_abort = reinterpret_cast<int *>(sync_);                                                                              \
-    unsigned *s_done = sync_ + 1, *s_stage = sync_ + 3, *s_dy = sync_ + 5, *s_ol = sync_ + 6, *s_tab = sync_ + 7;               \
+    unsigned *s_stage = sync_ + 3, *s_dy = sync_ + 5, *s_ol = sync_ + 6, *s_tab = sync_ + 7;                                    \
+    /* s_done[half][step parity]: images written, 8 per step of that parity.  Per parity because a product wave fed by     */  \
+    /* other workgroups can be one step (never two) ahead of a wave of its own workgroup that waits for a slow load: with   */  \
+    /* one count per half its early count would stand in for the late wave's missing one.                                   */  \
+    unsigned *s_done = sync_ + 8;                                                                                               \
     float *red = lds + BWDH_SYNC;     /* [half][step parity][8 * WS] */                                                         \
     float *ytmp = red + BWDH_RED;     /* wave 11: [column*16 + unit][k-class Y] of the half it is folding */                    \
     float *dhyb = ytmp + BWDH_YTMP;   /* [step & 3][column][unit]: Why^T dy of the step */                                      \
@@ -1416,7 +1425,7 @@ c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.w, c3, 2, 3, 0);
 #pragma unroll
             for (int r = 0; r < 4; r++) rp[64 * r] = (c0[r] + c1[r]) + (c2[r] + c3[r]); // register r = column r of the half
             asm volatile("" ::: "memory");
-            if (l == 0) __hip_atomic_fetch_add(&s_done[hf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (l == 0) __hip_atomic_fetch_add(&s_done[2 * hf + (t & 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (hf == 0) { HSTAMP(3, 11) } else { HSTAMP(3, 7) }
         }
     }
@@ -1461,7 +1470,8 @@ template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_elementwis
         HSTAMP(8, 0)
         float dhn = 0.0f;
         if (t < S - 1) {
-            if (!lds_wait(&s_done[hf], 8u * (unsigned)(S - 1 - t))) {
+            // product steps S-2 .. t of the parity of t: (S - t) / 2 of them
+            if (!lds_wait(&s_done[2 * hf + (t & 1)], 8u * (unsigned)((S - t) / 2))) {
                 give_up();
                 break;
             }
@@ -1761,7 +1771,7 @@ template <bool FUSE, bool STAMP = false> __global__ __launch_bounds__(BWDH_THREA
     BWDH_COMMON(p)
     if (tid == 0) {
         *s_abort = 0;
-        s_done[0] = s_done[1] = 0;
+        s_done[0] = s_done[1] = s_done[2] = s_done[3] = 0;
         s_stage[0] = s_stage[1] = 0;
         *s_dy = *s_ol = 0;
         *s_tab = 0;
