@@ -2373,7 +2373,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
 // host side
 // ------------------------------------------------------------------------------------------------
 size_t persistent_counter_bytes(int S, int B) {
-    const int NG = (B + 7) / 8; // the narrowest column groups in use
+    const int NG = (B + 3) / 4; // the narrowest column groups in use (bf16 backward recurrence at small batches)
     return (size_t)(S + 1) * NG * CNT_SLOTS * CNT_STRIDE * sizeof(unsigned);
 }
 
@@ -2464,6 +2464,7 @@ static int bwd_bf16_blocks(int N, int cols, bool fused) {
 #define X(k)                                                                                             \
     case k:                                                                                              \
         bb = cols == 16 ? blocks_per_cu(k_bwd_persistent<k, 16, false, false, true>, 512, 0)             \
+             : cols == 4 ? blocks_per_cu(k_bwd_persistent<k, 4, false, false, true>, 512, 0)             \
              : fused    ? blocks_per_cu(k_bwd_persistent<k, 8, true, false, true>, 512, DW_TABLE_BYTES)  \
                         : blocks_per_cu(k_bwd_persistent<k, 8, false, false, true>, 512, 0);             \
         break;
@@ -2473,6 +2474,11 @@ static int bwd_bf16_blocks(int N, int cols, bool fused) {
     return bb;
 }
 int bwd_group_cols_bf16(int N, int B, int n_cus, bool fused) {
+    // 4-column groups when even 8-column groups would leave half the CUs idle (BASELINE configs[4]: hidden 1024, 16 streams
+    // per GPU = 128 workgroups of 8 columns): twice the CUs, each pulling and multiplying half as much per step
+    if (!fused && B % 4 == 0 && (size_t)(N / 16) * ((B + 7) / 8) * 2 <= (size_t)n_cus &&
+        grid_fits((size_t)(N / 16) * (B / 4), bwd_bf16_blocks(N, 4, false), n_cus))
+        return 4;
     if (grid_fits((size_t)(N / 16) * ((B + 7) / 8), bwd_bf16_blocks(N, 8, fused), n_cus)) return 8;
     return 16;
 }
@@ -2653,6 +2659,7 @@ void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float
 #define X(k)                                                  \
     case k:                                                   \
         if (cols == 16) BWD_GO(k, 16, false, false, true);    \
+        else if (cols == 4) BWD_GO(k, 4, false, false, true); \
         else if (fuse) BWD_GO(k, 8, true, false, true);       \
         else BWD_GO(k, 8, false, false, true);                \
         break;
