@@ -87,7 +87,7 @@ int bwd_ring_advance(int ring_base, int S);
 void pack_U_bf16(const float *U, void *Ufwd16, void *Ubwd16, int N, hipStream_t st);
 void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, float *H, unsigned short *Hb, float *C,
                          float *G, const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
-                         bool fast, hipStream_t st);
+                         bool fast, hipStream_t st, int n_cus);
 size_t bwd_partial_floats(int N);
 int bwd_group_cols(int N, int B, int n_cus); // 8 or 16 batch columns per backward workgroup
 

@@ -145,6 +145,7 @@ struct lstm_hip_ctx {
     float4 *Ufwd = nullptr, *Ubwd = nullptr;
     float4 *Ubwd4 = nullptr; // weight image of the 4x4x1 backward form (kernels.hip, k_pack_U), when bwd_uses_m4
     float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel (fwd_uses_8col_form) or, fwd_cols4, of the two-half one
+    int n_cus = 0;           // compute units of the device (grid choices)
     void *blas = nullptr;    // rocBLAS handle on `st` (null: k_gemm serves the time-batched products)
     bool blas_Y = false, blas_dU = false; // which of the two products go through it: whichever was faster at create
     bool side_stream = true; // LSTM_HIP_NO_SIDE_STREAM=1 (per handle): keep the whole window on one stream
@@ -283,7 +284,7 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
             h->packed16 = true;
         }
         RUN(K_FWD_PERSIST, fwd_persistent_bf16(h->Ufwd16, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi,
-                                               h->cnt, h->abortp, h->fwd_epoch, N, S, B, fast, h->st));
+                                               h->cnt, h->abortp, h->fwd_epoch, N, S, B, fast, h->st, h->n_cus));
     } else if (h->Hx && h->fwd_cols4) {
         RUN(K_FWD_PERSIST, fwd_persistent6(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
                                            h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st, h->stamps));
@@ -661,6 +662,7 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     const bool want_fused = !(cfg->flags & (LSTM_HIP_NO_FUSED_GRADS | LSTM_HIP_BF16_RECURRENCE)) && cfg->N <= 512; // larger N: one workgroup per CU no longer holds
     h->persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) &&                          // the dW table beside the weights
                     persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount, want_fused);
+    h->n_cus = prop.multiProcessorCount;
     h->bwd_cols = bwd_group_cols(cfg->N, cfg->B, prop.multiProcessorCount);
     if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) { // refusals: lstm_hip_create, before anything is allocated
         h->persistent = true;                    // ... where the bf16 kernels' own grids were checked

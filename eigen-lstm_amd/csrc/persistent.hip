@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_fwd_persistent_bf16(const u32x4 *__rest
 // bf16 recurrence, second form (see k_fwd_persistent2): 8 units per workgroup, K over 8 waves, every loaded fragment
 // of bf16(h_{t-1}) feeds two MFMA tiles.  N = 256*NKS2.
 // ------------------------------------------------------------------------------------------------
-template <int NKS2, bool FAST>
+template <int NKS2, bool FAST, int COLS = 16>
 __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__restrict__ Ufwd16, const float *__restrict__ W,
                                                               const float *__restrict__ bias, float *__restrict__ H,
                                                               unsigned short *Hb, float *__restrict__ C,
@@ -1102,7 +1102,10 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
     const int lin_ = blockIdx.x + NB2 * blockIdx.y;
     const int p2 = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
     const int q = l >> 4, c = l & 15;
-    const int col = 16 * g + c, colc = col < B ? col : B - 1;
+    // COLS = 8: half the tile columns carry no data (lanes c >= 8 load nothing and store nothing) -- the matrix pipe is not
+    // what bounds a step, and 8-column groups put twice as many CUs to work on half the h bytes each (small batches)
+    const bool live = c < COLS;
+    const int col = COLS * g + (c & (COLS - 1)), colc = col < B ? col : B - 1;
     const int p = 2 * p2 + (w & 1); // the row tile a gating wave (w < 2) finishes
     const int j = 4 * p + q;
 
@@ -1143,11 +1146,12 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
             const float *hp = H + (size_t)colc * N + 32 * (w * NKS2) + 8 * q;
 #pragma unroll
             for (int i = 0; i < NKS2; i++)
-                b[i] = pack_bf16x8(*reinterpret_cast<const float4 *>(hp + 32 * i), *reinterpret_cast<const float4 *>(hp + 32 * i + 4));
+                b[i] = live ? pack_bf16x8(*reinterpret_cast<const float4 *>(hp + 32 * i), *reinterpret_cast<const float4 *>(hp + 32 * i + 4))
+                            : u32x4{0u, 0u, 0u, 0u};
         } else {
             const int off = (int)((((size_t)(t - 1) * B + colc) * N + 32 * (w * NKS2) + 8 * q) * sizeof(unsigned short));
 #pragma unroll
-            for (int i = 0; i < NKS2; i++) b[i] = __builtin_amdgcn_raw_buffer_load_b128(rHb, off + 64 * i, 0, 16);
+            for (int i = 0; i < NKS2; i++) b[i] = live ? __builtin_amdgcn_raw_buffer_load_b128(rHb, off + 64 * i, 0, 16) : u32x4{0u, 0u, 0u, 0u};
         }
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1181,7 +1185,7 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
             h4.y = __shfl(hv, 16 + c, 64);
             h4.z = __shfl(hv, 32 + c, 64);
             h4.w = __shfl(hv, 48 + c, 64);
-            if (q == 0 && col < B) { // the hand-off copy: 4 units as bf16 = one 8-byte sc1 store
+            if (q == 0 && live && col < B) { // the hand-off copy: 4 units as bf16 = one 8-byte sc1 store
                 const unsigned long long pk = (unsigned long long)pack_bf16x2(h4.x, h4.y) |
                                               ((unsigned long long)pack_bf16x2(h4.z, h4.w) << 32);
                 __hip_atomic_store(reinterpret_cast<unsigned long long *>(Hb + ((size_t)t * B + col) * N + 4 * p), pk,
@@ -1193,7 +1197,7 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
                     __hip_atomic_fetch_add(cnt + ((size_t)(t * NG + g) * CNT_SLOTS + (p & (FWD_SH - 1))) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (col < B) {
+            if (live && col < B) {
                 if (q == 0) *reinterpret_cast<float4 *>(H + ((size_t)t * B + col) * N + 4 * p) = h4;
                 float *gc = G + ((size_t)t * B + col) * G4 + j;
                 gc[0] = ig;
@@ -2574,11 +2578,31 @@ void fwd_persistent6(const float4 *Ufwd5, const float *W, const float *bias, flo
                            ring_base, S, B, poll_cfg, nullptr);
 }
 
+// 8-column groups in the bf16 forward recurrence (second form) when 16-column groups would leave half the CUs idle
+static int fwd_bf16_cols(int N, int B, int n_cus) {
+    return N % 256 == 0 && B % 8 == 0 && (size_t)(N / 8) * ((B + 15) / 16) * 2 <= (size_t)n_cus &&
+                   (size_t)(N / 8) * (B / 8) <= (size_t)n_cus
+               ? 8
+               : 16;
+}
 void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, float *H, unsigned short *Hb, float *C,
                          float *G, const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
-                         bool fast, hipStream_t st) {
+                         bool fast, hipStream_t st, int n_cus) {
     const u32x4 *U16 = reinterpret_cast<const u32x4 *>(Ufwd16);
     if (N % 256 == 0) {
+        if (fwd_bf16_cols(N, B, n_cus) == 8) {
+            const dim3 grid8(N / 8, (B + 7) / 8), block2(512);
+            switch (N / 256) {
+#define X(k)                                                                                                             \
+    case k:                                                                                                              \
+        if (fast) hipLaunchKernelGGL((k_fwd_persistent2_bf16<k, true, 8>), grid8, block2, 0, st, U16, W, bias, H, Hb, C, G, xi, cnt, abortp, epoch, S, B); \
+        else hipLaunchKernelGGL((k_fwd_persistent2_bf16<k, false, 8>), grid8, block2, 0, st, U16, W, bias, H, Hb, C, G, xi, cnt, abortp, epoch, S, B);    \
+        break;
+                X(1) X(2) X(4)
+#undef X
+            }
+            return;
+        }
         const dim3 grid2(N / 8, (B + 15) / 16), block2(512);
         switch (N / 256) {
 #define X(k)                                                                                                             \
