@@ -53,7 +53,7 @@ __device__ __forceinline__ size_t ubwd4_index(int gk, int hr, int N) { // float 
     const int l = 32 * xp + 16 * y + (hr & 15);
     return ((((size_t)(hr >> 4) * 8 + w) * (N / 32) + m) * 64 + l) * 4 + zp;
 }
-//   Ufwd4[kb][w][pass][L][eh][sh][l].c (optional; third form of the forward recurrence, k_fwd_persistent3): wave w of
+//   Ufwd4[kb][w][pass][L][eh][sh][l].c (optional; the 8-column one-recurrence form of the forward recurrence, k_fwd_persistent4): wave w of
 //        workgroup kb owns input indices [Kw*w, Kw*(w+1)), Kw = N/8; lane l = 32x' + 4u + j; slot s = 4*sh + c;
 //        = U[gate j of unit 16*kb + 8*pass + u][Kw*w + 32*L + 4*s + 2*eh + x']
 __device__ __forceinline__ size_t ufwd4_index(int row, int k, int N) { // float index of U[row][k] in Ufwd4

@@ -8,19 +8,29 @@
 // REGISTERS for the whole window and the steps are chained inside the launch by a device-scope
 // hand-off.
 //
-// Decomposition (forward): workgroup (p, g) owns hidden units 4p..4p+3 -- one 16-row MFMA tile whose
-// rows are (unit, gate) so a lane ends up with i,o,f,u of one unit in its 4 accumulator registers --
-// for batch-column group g (16 columns).  Its 4 waves split K = N; each keeps its quarter of the
-// tile's U rows as 16x16x4 A-fragments in VGPRs.  Column groups are independent recurrences, so
-// the (p, g) workgroups of different g that share a CU overlap each other's hand-off latency.
+// This file holds several generations of that idea; the host side (end of the file) picks one per shape:
+//   forward   k_fwd_persistent6   N = 512, 8-column groups: two alternating 4-column recurrences per workgroup, 4x4x1 MFMA
+//                                 blocks, data-as-flag ring, no workgroup barrier                         (the headline shape)
+//             k_fwd_persistent4   N = 256 / 1024, 8-column groups: one recurrence per workgroup, same ring, one barrier
+//             k_fwd_persistent2   second form: 8 units x 16 columns on 16x16x4 tiles, counters   (small N, B <= 8, bf16 twin)
+//             k_fwd_persistent    first form: 4 units x 16 columns, counters                     (N = 64 multiples, bf16 twin)
+//   backward  k_bwd_halves        N = 512, 8-column groups: two alternating 4-column recurrences, side waves for the
+//                                 output-layer term and the dW / db / dWhy sums                           (the headline shape)
+//             k_bwd_persistent    everything else: 16x16x4 tiles or 4x4x1 blocks, 4 / 8 / 16-column groups, fp32 or bf16,
+//                                 sharded counters (or the ring, LSTM_HIP_BWD_HANDOFF=flag), optional fused sums
 //
-// Hand-off (cdna_hip_programming.md Guideline 16, counter form): the producing wave stores its slice
-// of h_t with sc1 (write-through) 16-byte stores, drains them (s_waitcnt vmcnt(0)), then ONE lane
-// does a relaxed agent-scope atomic add on a counter sharded 8 ways (cnt[t][g][p&7]) so arrivals do
-// not serialise on one address.  A consumer's wave 0 polls the 8 shards with sc1 loads until every
-// shard has all its arrivals, a workgroup barrier follows, and only then does any wave read h_t, with
-// sc1 loads (never through L1).  Counters are never reset: launch number e waits for e x arrivals.  Every
-// spin is bounded; on time-out a global abort word makes every workgroup leave, and the host reports it.
+// Hand-off, counter form (first / second forward forms, k_bwd_persistent; cdna_hip_programming.md Guideline 16): the
+// producing wave stores its slice of h_t with sc1 (write-through) 16-byte stores, drains them (s_waitcnt vmcnt(0)), then ONE
+// lane does a relaxed agent-scope atomic add on a sharded counter (cnt[t][g][shard]) so arrivals do not serialise on one
+// address.  A consumer's wave 0 polls the shards with sc1 loads until every shard has all its arrivals, a workgroup barrier
+// follows, and only then does any wave read h_t, with sc1 loads (never through L1).  Counters are never reset: launch number
+// e waits for e x arrivals.
+// Hand-off, data-as-flag form (k_fwd_persistent4 / 6, k_bwd_halves): see HX_RING below -- a ring of step slots whose words
+// hold a sentinel until the value is stored; consumers re-issue the loads of their own K-slice until no word is the
+// sentinel.  No counters, no drain, no barrier ahead of the loads.
+// When a column group's workgroups are verified (per launch, HW_REG_XCC_ID) to sit on one XCD, the payload is published
+// with plain stores that stay in that XCD's L2.
+// Every spin is bounded; on time-out a global abort word makes every workgroup leave, and the host reports it.
 //
 // Residency: all workgroups must be co-resident (they wait on each other); the host checks the grid
 // against the occupancy of the device and falls back to the per-step engine otherwise.
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(256) void k_fwd_persistent(const float4 *__restrict
 // fragment of h_{t-1} a lane loads feeds two MFMA tiles: half the load instructions per lane and half the bytes per
 // CU of the first form (a timing probe with half the loads removed from the first form: 387 -> 350 us).  Waves 0
 // and 1 each finish one row tile (gates, cell, publish, arrive): to the counters they are the producers 2p and
-// 2p+1 of the first form, so the counter protocol, k_wait_progress and the backward kernel see no difference.
+// 2p+1 of the first form, so the counter protocol and the backward kernel see no difference.
 // N = 128*NKW.
 // ------------------------------------------------------------------------------------------------
 template <int NKW, bool FAST>
