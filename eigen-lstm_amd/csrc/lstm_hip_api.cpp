@@ -422,10 +422,18 @@ int do_backward(lstm_hip_ctx *h) {
     } else if (fused) { // accumulated per column group inside the recurrence: fold the groups in order
         const int NGb = (B + h->bwd_cols - 1) / h->bwd_cols;
         const size_t psz = bwd_partial_floats(N);
-        // b and Why are adjacent both in the flat block and in the partial blocks: one fold covers both
-        RUN(K_DW_DB, (gemm_fold(h->gpart, NGb, G4 * 256, 1, h->dP + h->pl.W, G4 * 256, h->st, psz),
+        // b and Why are adjacent both in the flat block and in the partial blocks: one fold covers both.  With the early
+        // all-reduce below the folds go to st2 with it, so the dU product on `st` does not wait for them.
+        const bool on_st2 = h->comm && h->in_loop && !h->profiling;
+        hipStream_t fs = h->st;
+        if (on_st2) {
+            HIP_TRY(hipEventRecord(h->ev_fork, h->st));
+            HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+            fs = h->st2;
+        }
+        RUN(K_DW_DB, (gemm_fold(h->gpart, NGb, G4 * 256, 1, h->dP + h->pl.W, G4 * 256, fs, psz),
                       gemm_fold(h->gpart + (size_t)G4 * 256 + (size_t)G4 * N, NGb, G4 + 256 * N, 1, h->dP + h->pl.b,
-                                G4 + 256 * N, h->st, psz)));
+                                G4 + 256 * N, fs, psz)));
     } else if (side) {
         HIP_TRY(hipEventRecord(h->ev_mid, h->st)); // DG is complete
         HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_mid, 0));
@@ -438,8 +446,10 @@ int do_backward(lstm_hip_ctx *h) {
     // product: ranges [dW] and [db | dWhy | dby] of the flat block (one group).  The dU range follows on `st` behind the
     // product, ordered after ev_join, so the communicator never runs two collectives at once (do_allreduce).
     if (h->comm && h->in_loop && !h->profiling) {
-        HIP_TRY(hipEventRecord(h->ev_fork, h->st));
-        HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+        if (!fused) { // (fused: st2 already follows `st` from the end of the recurrence, with the folds queued on it)
+            HIP_TRY(hipEventRecord(h->ev_fork, h->st));
+            HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+        }
         int rc = 0;
         if (g_rccl.GroupStart && g_rccl.GroupEnd) g_rccl.GroupStart();
         rc = g_rccl.AllReduce(h->dP, h->dP, h->pl.U, /*ncclFloat*/ 7, /*ncclSum*/ 0, h->comm, h->st2);
@@ -454,7 +464,11 @@ int do_backward(lstm_hip_ctx *h) {
         // With the dU product in two column halves (rocBLAS path), the first half's all-reduce also goes on st2, behind the
         // early ranges and beside the second half's product; only the second half is left for `st`.
         h->dU_reduced = 0;
-        if (h->blas_dU && !h->bf16) {
+        // Off by default: the two half-size products cost 17.5 us more than the whole one (measured with a 1-rank
+        // communicator, tools/comm_overhead_probe.py), about what hiding half of the dU all-reduce can win back; to be
+        // decided on a real multi-GPU node (LSTM_HIP_DU_SPLIT=1).
+        static const bool du_split = getenv("LSTM_HIP_DU_SPLIT") && atoi(getenv("LSTM_HIP_DU_SPLIT")) != 0;
+        if (h->blas_dU && !h->bf16 && du_split) {
             const float one = 1.0f, zero = 0.0f;
             const int n1 = N / 2;
             int brc = g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_T, G4, n1, T, &one, h->DG + (size_t)G4 * B, G4, h->H, N, &zero,

@@ -645,32 +645,44 @@ def test_rccl_path_with_a_single_rank_communicator():
     assert np.array_equal(l0, l1) and np.array_equal(p0, p1)
 
 
-def test_rccl_path_at_the_headline_shape_splits_the_dU_all_reduce():
-    """With a communicator the dU product runs as two column halves (rocBLAS) and the first half's all-reduce goes out on
-    the second stream beside the second half's product.  1-rank communicator, headline shape: the trajectory must follow
-    the run without a communicator (not bit for bit: the half-size products may sum in another order)."""
-    import lstm_hip
-    N, S, B, windows = 512, 100, 64, 12
-    text = _synthetic_text(20000, seed=11)
-
-    def run(with_comm):
-        L = lstm_hip.Lstm(N, S, B)
-        L.set_params(lstm_hip.init_params(lstm_hip.MT19937Normal(5), N))
-        L.set_text(text)
-        L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
-        if with_comm:
-            L.comm_init(lstm_hip.comm_unique_id(), 1, 0)
-            L.set_global_batch(B)
-        losses = L.train_windows(windows, 0.01)
-        P = L.get_params()
-        L.close()
-        return losses, P
-
-    l0, p0 = run(False)
-    l1, p1 = run(True)
-    assert np.all(np.isfinite(l1))
-    assert np.max(np.abs(l1 - l0)) <= 1e-3 * np.max(np.abs(l0))
-    assert np.max(np.abs(p1 - p0)) <= 1e-4
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_rccl_path_at_the_headline_shape(split, monkeypatch):
+    """The communicator path at the headline shape (folds and early all-reduce on the second stream beside the dU product);
+    with LSTM_HIP_DU_SPLIT=1 the dU product runs as two column halves (rocBLAS) and the first half's all-reduce goes out
+    beside the second half's product.  1-rank communicator: the trajectory must follow the run without a communicator (not
+    bit for bit: the half-size products may sum in another order).  The switch is read once per process, so the two
+    settings run in child processes."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path[:0] = [{os.path.dirname(os.path.abspath(__file__))!r}, {os.path.join(ROOT, 'eigen-lstm_amd')!r}]
+        import lstm_hip
+        N, S, B, windows = 512, 100, 64, 12
+        text = np.random.RandomState(11).randint(32, 127, size=20000).astype(np.uint8)
+        def run(with_comm):
+            L = lstm_hip.Lstm(N, S, B)
+            L.set_params(lstm_hip.init_params(lstm_hip.MT19937Normal(5), N))
+            L.set_text(text)
+            L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
+            if with_comm:
+                L.comm_init(lstm_hip.comm_unique_id(), 1, 0)
+                L.set_global_batch(B)
+            losses = L.train_windows(windows, 0.01)
+            P = L.get_params()
+            L.close()
+            return losses, P
+        l0, p0 = run(False)
+        l1, p1 = run(True)
+        assert np.all(np.isfinite(l1))
+        assert np.max(np.abs(l1 - l0)) <= 1e-3 * np.max(np.abs(l0)), (l0, l1)
+        assert np.max(np.abs(p1 - p0)) <= 1e-4
+        print("OK")
+    """)
+    env = dict(os.environ, LSTM_HIP_DU_SPLIT=split)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
 
 
 def test_stride_variant_matches_oracle(oracle32):
