@@ -9,12 +9,12 @@
 // hand-off.
 //
 // This file holds several generations of that idea; the host side (end of the file) picks one per shape:
-//   forward   k_fwd_persistent6   N = 512, 8-column groups: two alternating 4-column recurrences per workgroup, 4x4x1 MFMA
+//   forward   k_fwd_persistent6   N = 512 / 256, 8-column groups: two alternating 4-column recurrences per workgroup, 4x4x1 MFMA
 //                                 blocks, data-as-flag ring, no workgroup barrier                         (the headline shape)
-//             k_fwd_persistent4   N = 256 / 1024, 8-column groups: one recurrence per workgroup, same ring, one barrier
+//             k_fwd_persistent4   N = 1024, 8-column groups: one recurrence per workgroup, same ring, one barrier
 //             k_fwd_persistent2   second form: 8 units x 16 columns on 16x16x4 tiles, counters   (small N, B <= 8, bf16 twin)
 //             k_fwd_persistent    first form: 4 units x 16 columns, counters                     (N = 64 multiples, bf16 twin)
-//   backward  k_bwd_halves        N = 512, 8-column groups: two alternating 4-column recurrences, side waves for the
+//   backward  k_bwd_halves        N = 512 / 256, 8-column groups: two alternating 4-column recurrences, side waves for the
 //                                 output-layer term and the dW / db / dWhy sums                           (the headline shape)
 //             k_bwd_persistent    everything else: 16x16x4 tiles or 4x4x1 blocks, 4 / 8 / 16-column groups, fp32 or bf16,
 //                                 sharded counters (or the ring, LSTM_HIP_BWD_HANDOFF=flag), optional fused sums
@@ -700,15 +700,16 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent4(const float4 *
 #define FSTAMP(wave, k)                                                                                        \
     if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
         stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = __builtin_amdgcn_s_memtime();
-template <bool FAST, bool STAMP = false>
+template <int N_, bool FAST, bool STAMP = false>
 __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *__restrict__ Ufwd5, const float *__restrict__ W,
                                                                   const float *__restrict__ bias, float *H, float *__restrict__ C,
                                                                   float *__restrict__ G, const int32_t *__restrict__ xi,
                                                                   float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch,
                                                                   int ring_base, int S, int B, int poll_cfg,
                                                                   unsigned long long *stamps = nullptr) {
-    constexpr int N = 512, G4 = 4 * N, Kw = N / 8, RS = 68; // RS: padded row of the partial-sum image (bank spread)
-    static_assert(Kw == 64, "one 16-byte load per lane covers a wave's K-slice of a half");
+    constexpr int N = N_, G4 = 4 * N, Kw = N / 8, RS = 68; // RS: padded row of the partial-sum image (bank spread)
+    constexpr int NAB = Kw / 4; // 16-byte pieces (= lane blocks that carry data) in a wave's K-slice of a half: 16 or 8
+    static_assert(N == 512 || N == 256, "one 16-byte load per lane covers a wave's K-slice of a half (N = 256: half the lanes)");
     __shared__ __attribute__((aligned(16))) float red[2][2][8 * 4 * RS]; // [half][step parity][wave][column][4*unit + gate]
     __shared__ int s_abort;
     // Per half and STEP PARITY: partial-sum images written so far, summed over the product waves (8 per step of that parity).
@@ -738,9 +739,10 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
     if (w < 8) {
         // ---------------- waves 0-7: the product, half A then half B ----------------
         const int lb = l >> 2, li = l & 3; // lane = 4*block + i
-        float4 wq[16];
+        const bool ld_lane = lb < NAB; // N = 256: blocks 8-15 have nothing to fetch (their registers read as complete)
+        float4 wq[NAB];
 #pragma unroll
-        for (int ab = 0; ab < 16; ab++) wq[ab] = Ufwd5[(((size_t)kb * 8 + w) * 16 + ab) * 64 + l];
+        for (int ab = 0; ab < NAB; ab++) wq[ab] = Ufwd5[(((size_t)kb * 8 + w) * NAB + ab) * 64 + l];
         int colv[2];
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
@@ -750,7 +752,8 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
         // h_0 of both halves (plain window state in H); later fragments come from the ring, requested a half-step ahead
         float4 bvq[2];
 #pragma unroll
-        for (int hf = 0; hf < 2; hf++) bvq[hf] = ld_sc1(rH, (int)((((size_t)colv[hf]) * N + Kw * w + 4 * lb) * sizeof(float)));
+        for (int hf = 0; hf < 2; hf++)
+            bvq[hf] = ld_lane ? ld_sc1(rH, (int)((((size_t)colv[hf]) * N + Kw * w + 4 * lb) * sizeof(float))) : float4{0.f, 0.f, 0.f, 0.f};
         for (int t = 1; t < S; t++) {
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
                     const int off = (int)((((size_t)slot * B + colv[hf]) * N + Kw * w + 4 * lb) * sizeof(float));
                     bool ok = false;
                     for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
-                        bv = ld_sc1(rHx, off);
+                        bv = ld_lane ? ld_sc1(rHx, off) : float4{0.f, 0.f, 0.f, 0.f};
                         if (__all(hx_ready(bv))) {
                             ok = true;
                             break;
@@ -794,10 +797,11 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
     c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv.y, wq[ab].y, c1, 4, ab, 0); \
     c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv.z, wq[ab].z, c2, 4, ab, 0); \
     c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(bv.w, wq[ab].w, c3, 4, ab, 0);
-                F6(0) F6(1) F6(2) F6(3) F6(4) F6(5) F6(6) F6(7) F6(8) F6(9) F6(10) F6(11) F6(12) F6(13) F6(14) F6(15)
+                F6(0) F6(1) F6(2) F6(3) F6(4) F6(5) F6(6) F6(7)
+                if constexpr (NAB == 16) { F6(NAB - 8) F6(NAB - 7) F6(NAB - 6) F6(NAB - 5) F6(NAB - 4) F6(NAB - 3) F6(NAB - 2) F6(NAB - 1) }
 #undef F6
                 __builtin_amdgcn_sched_barrier(0);
-                if (req) bvq[hf ^ 1] = ld_sc1(rHx, noff); // behind the last matrix instruction (ahead of them: 236-240 us)
+                if (req) bvq[hf ^ 1] = ld_lane ? ld_sc1(rHx, noff) : float4{0.f, 0.f, 0.f, 0.f}; // behind the last matrix instruction (ahead of them: 236-240 us)
                 __builtin_amdgcn_sched_barrier(0);
                 if (hf == 0) { FSTAMP(3, 10) } else { FSTAMP(3, 6) }
                 // lane (unit, gate j), register i = column i of the half: one row of the image per (wave, column)
@@ -1268,7 +1272,8 @@ struct BwdhArgs {
 };
 constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -, s_stage[2], s_dy, s_ol, s_tab, s_done[2][2]
 #define BWDH_COMMON(p)                                                                                                          \
-    constexpr int N = 512, G4 = 4 * N, Kw = N / 2, NL = Kw / 64; /* NL 16-byte loads per lane, half and step */                 \
+    constexpr int N = N_, G4 = 4 * N, Kw = N / 2, NL = Kw / 64; /* NL 16-byte loads per lane, half and step */                  \
+    static_assert(N == 512 || N == 256, "two-half backward form: hidden 512 or 256");                                           \
     constexpr int WS = 256;                                      /* partial-sum image: [wave][column*16 + unit][Y] */           \
     extern __shared__ __attribute__((aligned(16))) float lds[];                                                                 \
     unsigned *sync_ = reinterpret_cast<unsigned *>(lds);                                                                        \
@@ -1334,7 +1339,7 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -
         (void)ytmp, (void)dhyb, (void)stage, (void)dWt, (void)base, (void)dbs, (void)Kw, (void)NL, (void)WS,         \
         (void)kb, (void)w;
 
-template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_product(const BwdhArgs &p) {
+template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_product(const BwdhArgs &p) {
     BWDH_COMMON(p)
     bool live = true; // false: this wave has left the loop on an abort
     __builtin_amdgcn_s_setprio(2); // below the elementwise waves (3), above the side waves 10 and 11 (0)
@@ -1456,7 +1461,7 @@ c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.w, c3, 2, 3, 0);
         }
     }
 }
-template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_elementwise(const BwdhArgs &p) {
+template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_elementwise(const BwdhArgs &p) {
     BWDH_COMMON(p)
     // ---------------- elementwise waves: wave 8 half A, wave 9 half B; lane = column*16 + unit ----------------
     const int hf = w - 8;
@@ -1606,7 +1611,7 @@ template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_elementwis
         __syncthreads();
     }
 }
-template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_output_layer(const BwdhArgs &p) {
+template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_output_layer(const BwdhArgs &p) {
     BWDH_COMMON(p)
     // ---------------- wave 11: the output-layer term dhy_t = Why^T dy_t (R/lstm.cc:228), ahead of the chain ----------------
     // The product waves' arrangement with K = 256: lane (Y, z', i) loads dy_t[m = 64q + 16Y + 4z' + r][column 4*half + i]
@@ -1695,7 +1700,7 @@ template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_output_lay
         __syncthreads();
     }
 }
-template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_weight_sums(const BwdhArgs &p) {
+template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_weight_sums(const BwdhArgs &p) {
     BWDH_COMMON(p)
     // ---------------- wave 10: the weight-gradient sums that stay in the workgroup ----------------
     //   dW[:, x] += dg_t[:, column]  (R/lstm.cc:251)  one lane per row (gate*16 + unit) of the workgroup, [257][64] LDS table
@@ -1781,7 +1786,7 @@ template <bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_weight_sum
             for (int i = 0; i < 4; i++) Yp[(size_t)(4 * q + i) * 256 + 64 * mg] = acc[4 * mg + q][i];
     __syncthreads();
 }
-template <bool FUSE, bool STAMP = false> __global__ __launch_bounds__(BWDH_THREADS) void k_bwd_halves(const BwdhArgs p) {
+template <int N_, bool FUSE, bool STAMP = false> __global__ __launch_bounds__(BWDH_THREADS) void k_bwd_halves(const BwdhArgs p) {
     BWDH_COMMON(p)
     if (tid == 0) {
         *s_abort = 0;
@@ -1798,10 +1803,10 @@ template <bool FUSE, bool STAMP = false> __global__ __launch_bounds__(BWDH_THREA
     if (FUSE)
         for (int i = tid; i < 257 * 64; i += BWDH_THREADS) dWt[i] = 0.0f;
     __syncthreads();
-    if (w < 8) bwdh_product<FUSE, STAMP>(p);
-    else if (w < 10) bwdh_elementwise<FUSE, STAMP>(p);
-    else if (w == 11) bwdh_output_layer<FUSE, STAMP>(p);
-    else if (FUSE) bwdh_weight_sums<FUSE, STAMP>(p);
+    if (w < 8) bwdh_product<N_, FUSE, STAMP>(p);
+    else if (w < 10) bwdh_elementwise<N_, FUSE, STAMP>(p);
+    else if (w == 11) bwdh_output_layer<N_, FUSE, STAMP>(p);
+    else if (FUSE) bwdh_weight_sums<N_, FUSE, STAMP>(p);
 }
 #undef HSTAMP
 
@@ -2432,7 +2437,8 @@ bool persistent_supported(int N, int B, int n_cus, bool fused) {
     size_t fwd_grid = 0;
     if (fwd_uses_8col_form(N, B, n_cus)) {
         fwd_grid = (size_t)(N / 16) * ((B + 7) / 8);
-        if (N == 512 && blocks_per_cu(k_fwd_persistent6<false>, FWD4_THREADS) < 1) return false;
+        if (N == 512 && blocks_per_cu(k_fwd_persistent6<512, false>, FWD4_THREADS) < 1) return false;
+        if (N == 256 && blocks_per_cu(k_fwd_persistent6<256, false>, FWD4_THREADS) < 1) return false;
         switch (N / 256) {
 #define X(k) case k: fb = blocks_per_cu(k_fwd_persistent4<k, false>, FWD4_THREADS); break;
             X(1) X(2) X(4)
@@ -2571,21 +2577,25 @@ void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, flo
     }
 }
 
-// two-half form (k_fwd_persistent6): N = 512 on the grid of the 8-column form
-bool fwd_uses_two_half_form(int N, int B, int n_cus) { return N == 512 && fwd_uses_8col_form(N, B, n_cus); }
+// two-half form (k_fwd_persistent6): N = 512 or 256 on the grid of the 8-column form
+bool fwd_uses_two_half_form(int N, int B, int n_cus) { return (N == 512 || N == 256) && fwd_uses_8col_form(N, B, n_cus); }
 void fwd_persistent6(const float4 *Ufwd5, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
                      int poll_cfg, hipStream_t st, unsigned long long *stamps) {
     const dim3 grid(N / 16, (B + 7) / 8), block(FWD4_THREADS);
-    if (stamps != nullptr)
-        hipLaunchKernelGGL((k_fwd_persistent6<false, true>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch,
-                           ring_base, S, B, poll_cfg, stamps);
-    else if (fast)
-        hipLaunchKernelGGL((k_fwd_persistent6<true>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch,
-                           ring_base, S, B, poll_cfg, nullptr);
-    else
-        hipLaunchKernelGGL((k_fwd_persistent6<false>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch,
-                           ring_base, S, B, poll_cfg, nullptr);
+#define F6_GO(...)                                                                                                            \
+    hipLaunchKernelGGL((k_fwd_persistent6<__VA_ARGS__>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch, \
+                       ring_base, S, B, poll_cfg, stamps)
+    if (N == 512) {
+        if (stamps != nullptr) F6_GO(512, false, true);
+        else if (fast) F6_GO(512, true);
+        else F6_GO(512, false);
+    } else {
+        stamps = nullptr; // (stamped builds exist for the headline shape)
+        if (fast) F6_GO(256, true);
+        else F6_GO(256, false);
+    }
+#undef F6_GO
 }
 
 // 8-column groups in the bf16 forward recurrence (second form) when 16-column groups would leave half the CUs idle
@@ -2643,10 +2653,15 @@ int bwd_ring_advance(int ring_base, int S) { return (ring_base - (S - 1)) & (HX_
 
 // two-half form of the backward recurrence (k_bwd_halves): N = 512, 8-column groups
 bool bwd_halves_supported(int N, int B, int n_cus, bool fused) {
-    if (N != 512 || bwd_group_cols(N, B, n_cus) != 8) return false;
+    if ((N != 512 && N != 256) || bwd_group_cols(N, B, n_cus) != 8) return false;
     const size_t grid = (size_t)(N / 16) * ((B + 7) / 8);
-    const int per_cu = fused ? blocks_per_cu(k_bwd_halves<true>, BWDH_THREADS, bwdh_lds_bytes(true))
-                             : blocks_per_cu(k_bwd_halves<false>, BWDH_THREADS, bwdh_lds_bytes(false));
+    int per_cu = 0;
+    if (N == 512)
+        per_cu = fused ? blocks_per_cu(k_bwd_halves<512, true>, BWDH_THREADS, bwdh_lds_bytes(true))
+                       : blocks_per_cu(k_bwd_halves<512, false>, BWDH_THREADS, bwdh_lds_bytes(false));
+    else
+        per_cu = fused ? blocks_per_cu(k_bwd_halves<256, true>, BWDH_THREADS, bwdh_lds_bytes(true))
+                       : blocks_per_cu(k_bwd_halves<256, false>, BWDH_THREADS, bwdh_lds_bytes(false));
     return per_cu >= 1 && grid <= (size_t)n_cus;
 }
 void bwd_halves(const float4 *Ubwd5, float *DG, const float *Why, const float *dY, const float *G, const float *C, const float *H,
@@ -2662,13 +2677,18 @@ void bwd_halves(const float4 *Ubwd5, float *DG, const float *Why, const float *d
         hipLaunchKernelGGL((k_bwd_halves<__VA_ARGS__>), grid, block, lds, st, args);                                                \
     } while (0)
     const BwdhArgs args = {Ubwd5, DG, Why, dY, G, C, H, xi, gpart, DGx, cnt, abortp, epoch, ring_base, S, B, cfg, stamps};
-    if (stamps != nullptr) {
-        if (fuse) BH_GO(true, true);
-        else BH_GO(false, true);
+    if (N == 256) { // (stamped builds exist for the headline shape)
+        const BwdhArgs args256 = {Ubwd5, DG, Why, dY, G, C, H, xi, gpart, DGx, cnt, abortp, epoch, ring_base, S, B, cfg, nullptr};
+        const BwdhArgs &args = args256;
+        if (fuse) BH_GO(256, true, false);
+        else BH_GO(256, false, false);
+    } else if (stamps != nullptr) {
+        if (fuse) BH_GO(512, true, true);
+        else BH_GO(512, false, true);
     } else if (fuse)
-        BH_GO(true, false);
+        BH_GO(512, true, false);
     else
-        BH_GO(false, false);
+        BH_GO(512, false, false);
 #undef BH_GO
 }
 

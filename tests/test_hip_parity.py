@@ -168,8 +168,10 @@ def test_backward_data_as_flag_handoff_matches_oracle(oracle32, monkeypatch):
     from oracle_lib import Oracle
     N, S, B = 256, 12, 64
     monkeypatch.setenv("LSTM_HIP_BWD_HANDOFF", "flag")
+    monkeypatch.setenv("LSTM_HIP_BWD_HALVES", "0")  # the one-recurrence form (the two-half form always uses the ring)
     L = lstm_hip.Lstm(N, S, B)
     monkeypatch.delenv("LSTM_HIP_BWD_HANDOFF")
+    monkeypatch.delenv("LSTM_HIP_BWD_HALVES")
     orc = Oracle("f32_omp")
     for rep in range(5):
         P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=300 + rep, empty=((1, rep),))
@@ -187,14 +189,15 @@ def test_backward_data_as_flag_handoff_matches_oracle(oracle32, monkeypatch):
 
 
 @pytest.mark.parametrize("fused,B", [(True, 60), (False, 60), (True, 59)])
-def test_backward_two_half_form_matches_oracle(oracle32, monkeypatch, fused, B):
+@pytest.mark.parametrize("N", [512, 256])
+def test_backward_two_half_form_matches_oracle(oracle32, monkeypatch, fused, B, N):
     """LSTM_HIP_BWD_HALVES=1 (read per handle at create): each workgroup of the backward recurrence advances its eight
     columns as two alternating 4-column recurrences (k_bwd_halves, N = 512 only), with the gradient sums dW, db, dWhy
     inside the kernel (fused) or left to the separate passes.  Same window, same tolerances, ragged batch (the last group
     has a padded half, B = 59 a padded column inside a half), ring reuse across launches."""
     import lstm_hip
     from oracle_lib import Oracle
-    N, S = 512, 11
+    S = 11
     monkeypatch.setenv("LSTM_HIP_BWD_HALVES", "1")
     L = lstm_hip.Lstm(N, S, B, flags=0 if fused else lstm_hip.NO_FUSED_GRADS)
     monkeypatch.delenv("LSTM_HIP_BWD_HALVES")
@@ -215,11 +218,12 @@ def test_backward_two_half_form_matches_oracle(oracle32, monkeypatch, fused, B):
 
 
 @pytest.mark.parametrize("S", [2, 3, 5])
-def test_two_half_forms_on_very_short_windows(oracle32, S):
+@pytest.mark.parametrize("N", [512, 256])
+def test_two_half_forms_on_very_short_windows(oracle32, S, N):
     """The two-half recurrences (N = 512) run their side waves up to four steps ahead of the chain and request fragments
     a half-step ahead: windows shorter than those look-aheads (S-1 = 1, 2, 4 timesteps) must still come out right."""
     import lstm_hip
-    N, B = 512, 64
+    B = 64
     P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=70 + S)
     fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
     dref = oracle32.backward(N, 256, S, B, P, xi, ti, fw)
@@ -925,7 +929,7 @@ def test_backward_declines_xcd_local_handoff_when_groups_span_xcds(tmp_path):
         "rep = gu.grads_report(L.get_grads(), dref, N)\n"
         "L.close()\n"
         "print('MAXREL', max(rep.values()))\n")
-    env = dict(os.environ, LSTM_HIP_BWD_SPREAD="1")
+    env = dict(os.environ, LSTM_HIP_BWD_SPREAD="1", LSTM_HIP_BWD_HALVES="0")  # the one-recurrence form's own switch
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     worst = float(out.stdout.strip().split("MAXREL")[-1])
