@@ -18,6 +18,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -771,12 +774,26 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
                 *out = best;
                 return 0;
             };
-            float tb = 0.f, to = 0.f;
-            int rc_ = 0;
-            if ((rc_ = best_ms(blas_Y, &tb)) || (rc_ = best_ms(own_Y, &to))) return rc_;
-            h->blas_Y = tb < 0.9f * to; // a clear win only: the choice should not flip from run to run
-            if ((rc_ = best_ms(blas_dU, &tb)) || (rc_ = best_ms(own_dU, &to))) return rc_;
-            h->blas_dU = tb < 0.9f * to;
+            // One decision per shape and process: handles of the same shape must compute alike (tests compare two of them bit
+            // for bit), and a timing that is close could otherwise fall either way.
+            static std::mutex choice_mu;
+            static std::map<std::tuple<int, int, int>, std::pair<bool, bool>> choice;
+            const std::tuple<int, int, int> key((int)N, h->T, h->cfg.device);
+            std::lock_guard<std::mutex> lk(choice_mu);
+            auto it = choice.find(key);
+            if (it == choice.end()) {
+                float tb = 0.f, to = 0.f;
+                int rc_ = 0;
+                if ((rc_ = best_ms(blas_Y, &tb)) || (rc_ = best_ms(own_Y, &to))) return rc_;
+                const bool by_ = tb < 0.9f * to; // a clear win only
+                if ((rc_ = best_ms(blas_dU, &tb)) || (rc_ = best_ms(own_dU, &to))) return rc_;
+                it = choice.emplace(key, std::make_pair(by_, tb < 0.9f * to)).first;
+            } else { // still make the first calls on this handle (kernel selection, workspace)
+                blas_Y();
+                blas_dU();
+            }
+            h->blas_Y = it->second.first;
+            h->blas_dU = it->second.second;
             HIP_TRY(hipStreamSynchronize(h->st));
             HIP_TRY(hipMemsetAsync(h->dP, 0, sizeof(float) * h->pl.total, h->st));
             HIP_TRY(hipMemsetAsync(h->Y, 0, sizeof(float) * 256 * S * B, h->st));
