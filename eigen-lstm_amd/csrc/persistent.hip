@@ -1334,6 +1334,7 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -
             base[(size_t)x * G4 + (r >> 4) * N + 16 * kb + (r & 15)] = dWt[i];                                                  \
         }                                                                                                                       \
     };                                                                                                                          \
+    (void)give_up, (void)lds_wait, (void)table_out, (void)S,                                                                    \
     (void)Ubwd5, (void)DG, (void)Why, (void)dY, (void)G, (void)C, (void)H, (void)xi, (void)epoch, (void)ring_base, (void)cfg,   \
         (void)stamps, (void)NBK, (void)rDG, (void)xcc_tab, (void)s_done, (void)s_stage, (void)s_dy, (void)s_ol, (void)s_tab,    \
         (void)ytmp, (void)dhyb, (void)stage, (void)dWt, (void)base, (void)dbs, (void)Kw, (void)NL, (void)WS,         \
