@@ -71,12 +71,15 @@ __device__ __forceinline__ size_t ufwd5_index(int row, int k, int N) { // float 
     return ((((size_t)(u >> 4) * 8 + w) * (Kw / 4) + (kk >> 2)) * 64 + l) * 4 + (kk & 3);
 }
 //   Ubwd5[kb][w][m][r][l].z' (the 4-column-half form of the backward recurrence, k_bwd_halves; stored through the Ubwd4
-//        pointer when bit 1 of `half_forms` is set): wave w of workgroup kb owns gate rows [Kw*w, Kw*(w+1)), Kw = N/2;
-//        lane l = 16Y + 4z + j;  = U[Kw*w + 64m + 16Y + 4z' + r][16*kb + 4z + j]
+//        pointer when bit 1 of `half_forms` is set): wave w of workgroup kb owns the gate rows of hidden units
+//        [UW*w, UW*(w+1)), UW = N/8 -- all four gates of a few producers, not one gate of many: a wave then waits for UW/16
+//        producer workgroups instead of N/32 -- in the order q = gate*UW + (unit - UW*w); lane l = 16Y + 4z + j;
+//        = U[row(q = 64m + 16Y + 4z' + r)][16*kb + 4z + j],  row(q) = (q / UW)*N + UW*w + q % UW
 __device__ __forceinline__ size_t ubwd5_index(int gk, int hr, int N) { // float index of U[gk][hr] in Ubwd5
-    const int Kw = N / 2, w = gk / Kw, kk = gk % Kw, m = kk >> 6, rem = kk & 63;
+    const int UW = N / 8, gate = gk / N, unit = gk % N, w = unit / UW, q = gate * UW + unit % UW;
+    const int m = q >> 6, rem = q & 63;
     const int Y = rem >> 4, zp = (rem >> 2) & 3, r = rem & 3, l = 16 * Y + (hr & 15);
-    return ((((((size_t)(hr >> 4) * 8 + w) * (Kw / 64) + m) * 4 + r) * 64 + l) * 4) + zp;
+    return ((((((size_t)(hr >> 4) * 8 + w) * (N / 128) + m) * 4 + r) * 64 + l) * 4) + zp;
 }
 // half_forms: bit 0 = the forward image is Ufwd5, bit 1 = the backward image is Ubwd5
 __device__ __forceinline__ size_t ufwd45_index(int row, int k, int N, int half_forms) {

@@ -1229,8 +1229,10 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
 // grid (N/16, ceil(B/8)), 704 threads.  The eight columns of workgroup (kb, g) are two independent recurrences of four
 // columns, A and B: while A's dg_t is computed elementwise, published and fetched by the group, the eight product waves
 // run B's  dhnext = U^T dg_{t+1}  and the other way round.
-//   waves 0-7  product; K = 4N split over the waves (Kw = N/2 gate rows each), v_mfma_f32_4x4x1 with block = 4Y + z:
-//                D[i][j] += dg[k = Kw*w + 64m + 16Y + 4z' + r][column 4*half + i] * U^T[unit 4z + j][k]
+//   waves 0-7  product; K = 4N split over the waves BY HIDDEN UNIT: wave w takes all four gate rows of units
+//              [N/8*w, N/8*(w+1)), i.e. what N/128 producer workgroups publish (by gate it would be one gate of N/32
+//              producers: every wave would wait for half the group; 340 -> 335 us).  v_mfma_f32_4x4x1 with block = 4Y + z:
+//                D[i][j] += dg[row(q = 64m + 16Y + 4z' + r)][column 4*half + i] * U^T[unit 4z + j][row(q)]
 //              CBSZ = 2 / ABID = z': the four z-blocks of a Y-group read their dg from block z' of the loaded register,
 //              so a lane's 16-byte load m (lane = 16Y + 4z' + i: 16 consecutive bytes of k, 256 per column) feeds
 //              sixteen instructions; weights Ubwd5 (ubwd5_index), 64 registers; 64 instructions per half and step.
@@ -1349,21 +1351,29 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_pr
     float4 a[4 * NL];
 #pragma unroll
     for (int i = 0; i < 4 * NL; i++) a[i] = Ubwd5[(((size_t)kb * 8 + w) * (4 * NL) + i) * 64 + l];
-    int cofs[2]; // float offset of this lane's first fragment inside a step slot
+    // This wave's K-slice: the four gates of hidden units [UW*w, UW*(w+1)) -- UW/16 producer workgroups -- in the order
+    // q = gate*UW + unit; fragment m of lane (Y, z') is rows q = 64m + 16Y + 4z' .. +3 (ubwd5_index packs U to match)
+    constexpr int UW = N / 8;
+    int cofs[2], mofs[NL]; // float offsets inside a step slot: this lane's column, and its fragment m inside the column
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
         const int c = 8 * g + 4 * hf + li, cc_ = c < B ? c : B - 1;
-        cofs[hf] = cc_ * G4 + Kw * w + 16 * lY + 4 * lz;
+        cofs[hf] = cc_ * G4;
     }
-    // hint: lane i < Kw/16 looks at producer workgroup i of this wave's K-slice (one gate, Kw consecutive units): the
-    // 16 bytes its elementwise wave stores from its last lane (column 3 of the half, units 12-15)
+#pragma unroll
+    for (int m = 0; m < NL; m++) {
+        const int q = 64 * m + 16 * lY + 4 * lz;
+        mofs[m] = (q / UW) * N + UW * w + q % UW;
+    }
+    // hint: lane i < UW/16 looks at producer workgroup i of this wave's K-slice: the 16 bytes its elementwise wave stores
+    // from its last lane (column 3 of the half, gate 3, units 12-15)
     const bool use_hint = (cfg & 1) != 0, spec_a = (cfg & 2) == 0;
     const int hint_sleep = (cfg >> 8) ? (cfg >> 8) - 1 : 1; // pauses of 64 cycles between hint polls (tuning; default 1)
     int hint_ofs[2];
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
         const int c = 8 * g + 4 * hf + 3, cc_ = c < B ? c : B - 1;
-        hint_ofs[hf] = cc_ * G4 + Kw * w + 16 * (l & (Kw / 16 - 1)) + 12;
+        hint_ofs[hf] = cc_ * G4 + 3 * N + UW * w + 16 * (l & (UW / 16 - 1)) + 12;
     }
     float4 bq[2][NL];
     // (epilogue of this role: at the end of the branch)
@@ -1389,7 +1399,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_pr
                     // (two hint requests in flight half a round trip apart: 360 us against 348 -- polls load the L2)
                     for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
                         float4 hv = {0.f, 0.f, 0.f, 0.f};
-                        if (l < Kw / 16) hv = ld_sc1(rDG, hoff);
+                        if (l < UW / 16) hv = ld_sc1(rDG, hoff);
                         if (__all(hx_ready(hv))) break;
                         if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                         for (int i = 0; i < hint_sleep; i++) __builtin_amdgcn_s_sleep(1);
@@ -1399,7 +1409,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_pr
                 for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
                     bool gd = true;
 #pragma unroll
-                    for (int m = 0; m < NL; m++) bq[hf][m] = ld_sc1(rDG, off + 256 * m);
+                    for (int m = 0; m < NL; m++) bq[hf][m] = ld_sc1(rDG, off + 4 * mofs[m]);
 #pragma unroll
                     for (int m = 0; m < NL; m++) gd = gd && hx_ready(bq[hf][m]);
                     if (__all(gd)) {
@@ -1436,7 +1446,7 @@ c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.w, c3, 2, 3, 0);
                 if (tn >= 1 && (hf == 0 || spec_a)) {
                     const int noff = slot_off(tn + 1, hf ^ 1);
 #pragma unroll
-                    for (int m = 0; m < NL; m++) bq[hf ^ 1][m] = ld_sc1(rDG, noff + 256 * m);
+                    for (int m = 0; m < NL; m++) bq[hf ^ 1][m] = ld_sc1(rDG, noff + 4 * mofs[m]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
