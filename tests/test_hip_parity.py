@@ -217,6 +217,20 @@ def test_backward_two_half_form_matches_oracle(oracle32, monkeypatch, fused, B, 
     L.close()
 
 
+@pytest.mark.parametrize("N,S,B", [(512, 6, 4), (512, 6, 12), (256, 7, 9), (256, 5, 1)])
+def test_two_half_backward_with_padded_halves(oracle32, N, S, B):
+    """Batches that leave a half-group (B = 4: all of half B; B = 12, 9, 1: part of a group) without real columns: the padded
+    lanes fetch a neighbour's data and must neither publish nor contribute to the weight-gradient sums."""
+    import lstm_hip
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=170 + B)
+    fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
+    dref = oracle32.backward(N, 256, S, B, P, xi, ti, fw)
+    got = _run_hip(lstm_hip, N, S, B, P, xi, ti, h0, c0)
+    assert abs(got["loss"] - fw["loss_bits"]) <= LOSS_TOL * (S - 1)
+    rep_ = gu.grads_report(got["grads"], dref, N)
+    assert max(rep_.values()) <= GRAD_TOL, rep_
+
+
 @pytest.mark.parametrize("S", [2, 3, 5])
 @pytest.mark.parametrize("N", [512, 256])
 def test_two_half_forms_on_very_short_windows(oracle32, S, N):
