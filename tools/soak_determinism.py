@@ -1,6 +1,6 @@
 """Soak: two handles, same seed and text, W windows each at the headline shape; the parameters must come out bit-identical
 (every kernel of the path is deterministic, so a difference would mean a race in a hand-off).
-  python tools/soak_determinism.py [windows]"""
+  python tools/soak_determinism.py [windows [N S B]]"""
 import os
 import sys
 
@@ -13,7 +13,7 @@ import lstm_hip  # noqa: E402
 from bench import synthetic_text  # noqa: E402
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 12000
-N, S, B = 512, 100, 64
+N, S, B = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (512, 100, 64)
 text = synthetic_text(1_000_000, seed=0)
 out = []
 for rep in range(2):
