@@ -59,10 +59,10 @@ if os.environ.get("LSTM_HIP_FWD_HALVES", "1") != "0":   # two-half form: wave 3 
         t = np.arange(3, S - 1)
         show(f"forward two-half form, workgroup {wg}: product wave 3 around the step", [
             ("half A: poll", s[t, 9] - s[t, 8]), ("half A: 64 MFMA", s[t, 10] - s[t, 9]),
-            ("half A: LDS + barrier X", s[t, 11] - s[t, 10]),
+            ("half A: partial sums to LDS + count", s[t, 11] - s[t, 10]),
             ("half B: poll", s[t, 5] - s[t, 11]), ("half B: 64 MFMA", s[t, 6] - s[t, 5]),
-            ("half B: LDS + barrier Y", s[t, 7] - s[t, 6]),
-            ("gating wave 8 (half A): X released -> published", s[t, 3] - s[t, 1]),
+            ("half B: partial sums to LDS + count", s[t, 7] - s[t, 6]),
+            ("gating wave 8 (half A): count complete -> published", s[t, 3] - s[t, 1]),
             ("half A published -> wave 3's next half-A poll complete", s[t + 1, 9] - s[t, 3]),
         ])
 
@@ -78,7 +78,7 @@ if os.environ.get("LSTM_HIP_BWD_HALVES", "7") != "0":   # two-half backward form
             ("product wave 3, half B: 64 MFMA + next requests issued", s[t, 6] - s[t, 5]),
             ("product wave 3, half B: sums to LDS + count", s[t, 7] - s[t, 6]),
             ("elementwise wave 8: operands requested -> count complete", s[t, 1] - s[t, 0]),
-            ("elementwise wave 8: fold (32 LDS reads) + elementwise + transpose", s[t, 2] - s[t, 1]),
+            ("elementwise wave 8: fold (8 x 16-byte LDS reads) + elementwise + transpose", s[t, 2] - s[t, 1]),
             ("elementwise wave 8: s_waitcnt vmcnt(0)", s[t, 3] - s[t, 2]),
             ("elementwise wave 8: publish + reset + DG store issued", s[t, 4] - s[t, 3]),
             ("count complete -> dg_t published (on the chain)", s[t, 3] - s[t, 1]),
@@ -90,9 +90,9 @@ if os.environ.get("LSTM_HIP_BWD_HALVES", "7") != "0":   # two-half backward form
     show("wave 11 (output layer ahead of the chain), workgroup 0", [
         ("period (loop top to loop top)", s[t - 1, 12] - s[t, 12]),
         ("wait for the slot (step t+4 consumed)", s[t, 13] - s[t, 12]),
-        ("tile to LDS (needs last step's loads) + next request", s[t, 14] - s[t, 13]),
-        ("128 LDS reads + 256 packed multiply-adds", s[t, 15] - s[t, 14]),
-        ("fold + dhy out + signal -> next loop top", s[t - 1, 12] - s[t, 15]),
+        ("128 instructions 4x4x1 + fold through LDS (needs last step's loads)", s[t, 14] - s[t, 13]),
+        ("next request + signal", s[t, 15] - s[t, 14]),
+        ("-> next loop top", s[t - 1, 12] - s[t, 15]),
         ("lead over the elementwise wave: its step-t start minus this wave's", s[t, 0] - s[t, 12]),
     ])
     tt = np.arange(S - 1, 0, -1)
