@@ -91,19 +91,25 @@ void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, 
 size_t bwd_partial_floats(int N);
 int bwd_group_cols(int N, int B, int n_cus); // 8 or 16 batch columns per backward workgroup
 
-// ---- time-batched dense products (fp32 MFMA 32x32x2, LDS tiled) ------------------------------
-// C[M x Nn] = op(A)[M x K] * op(B)[K x Nn], column-major; TA: A is stored K x M; TB: B is stored Nn x K.
-// splits > 1 writes `splits` partial slabs into `slabs` (each M*Nn floats, ld = M); gemm_reduce
-// sums them into C in slab order (deterministic).  `slabs` must hold splits*M*Nn floats.
+// ---- time-batched dense products (gemm.hip: fp32 MFMA 32x32x2, operands streamed into registers, K split over the waves
+//      of a workgroup) --------------------------------------------------------------------------
+// C[M x Nn] = op(A)[M x K] * op(B)[K x Nn], column-major; TA: A is stored K x M; TB: B is stored Nn x K.  (TA && TB is
+// not a product of the window and is refused.)  splits > 1 writes partial slabs into `slabs` (each M*Nn floats, ld = M)
+// and gemm_fold sums them into C in slab order (deterministic).  `slabs` must hold splits*M*Nn floats.
 void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
           int splits, float *slabs, hipStream_t st);
-int gemm_pick_splits(int M, int Nn, int K);
+// how many slabs the shape rule wants (1: no slabs); a static function of the shape and the device's compute-unit count
+int gemm_pick_splits(bool TA, bool TB, int M, int Nn, int K, int n_cus);
 // the ordered fold of `splits` slabs
 // slab_stride: floats between consecutive slabs (0 = M*Nn, i.e. densely packed)
 void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st, size_t slab_stride = 0);
 // the split-K product without its fold (slabs densely packed, M*Nn floats each); returns the number of slabs written
 int gemm_slabs(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *slabs, int splits,
                hipStream_t st);
+// the same by operand layout ("k fast": the contraction index is the contiguous one); gemm / gemm_slabs map onto these
+int gemm_regs_splits(bool a_kfast, bool b_kfast, int M, int Nn, int K, int n_cus);
+int gemm_regs(bool a_kfast, bool b_kfast, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+              int splits, float *slabs, hipStream_t st);
 
 // ---- bf16 time-batched products (LSTM_HIP_BF16_RECURRENCE): C[m + ldc*n] = sum_k A[m][k] * B[n][k], fp32 accumulate on
 //      v_mfma_f32_32x32x16_bf16.  A, B: bfloat16, k contiguous (lda, ldb in elements, multiples of 8; 16-byte aligned

@@ -345,219 +345,9 @@ void bwd_step(const float4 *Ubwd, const float *DGnext, const float *DHy_t, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// gemm: C = op(A) * op(B), fp32 MFMA 32x32x2, 128x128x16 LDS tiles, 4 waves each 64x64.
-// The MFMA is issued with the operands swapped (A-operand <- op(B) column index, B-operand <- op(A)
-// row index) so the accumulator holds C^T fragments: lanes then run along m, which is contiguous in
-// column-major C, and the epilogue stores are coalesced.
+// The fp32 time-batched products themselves live in gemm.hip (register-streamed 32x32x2 tiles); here only the ordered
+// fold of split-K slabs / per-group partial blocks, which the bf16 products and the fused backward recurrence also use.
 // ------------------------------------------------------------------------------------------------
-#ifndef GEMM_BK
-#define GEMM_BK 16
-#endif
-constexpr int GBK = GEMM_BK; // k-tile depth (16; 32 measured the same to slightly slower on dU: 141 vs 144 us); tile = (64*MW) x (64*NI) with 2*MW waves of 64 x (32*NI)
-
-// Tile loaders.  ROWS = tile rows (m or n), NT = threads.  TRANS=false: the source is [rows contiguous] x K
-// (a float4 is 4 consecutive rows of one k); TRANS=true: the source is K-contiguous (a float4 is 4
-// consecutive k of one row).  The LDS image is always [k][row] with row stride ROWS+4.
-template <bool TRANS, int ROWS, int NT> struct GemmTile {
-    static constexpr int LD = ROWS + 4;
-    static constexpr int K4 = GBK / 4; // float4 along k per row (TRANS)
-    static constexpr int REPS = TRANS ? (ROWS * K4 + NT - 1) / NT : (GBK * (ROWS / 4) + NT - 1) / NT;
-    static_assert(REPS >= 1 && REPS <= 4, "tile / thread-count combination not supported");
-    __device__ static __forceinline__ void load(const float *__restrict__ src, int ld, int r0, int rmax, int k0, int kend,
-                                                int tid, float4 (&reg)[4]) {
-#pragma unroll
-        for (int q = 0; q < REPS; q++) {
-            float4 v = {0.f, 0.f, 0.f, 0.f};
-            if (!TRANS) {
-                constexpr int R4 = ROWS / 4, KSTEP = NT / R4;
-                const int r = r0 + (tid % R4) * 4, k = k0 + tid / R4 + q * KSTEP;
-                if (k < kend && tid / R4 + q * KSTEP < GBK) {
-                    const float *p = src + (size_t)k * ld + r;
-                    if (r + 3 < rmax) v = *reinterpret_cast<const float4 *>(p);
-                    else {
-                        if (r < rmax) v.x = p[0];
-                        if (r + 1 < rmax) v.y = p[1];
-                        if (r + 2 < rmax) v.z = p[2];
-                    }
-                }
-            } else {
-                constexpr int RSTEP = NT / K4;
-                const int k = k0 + (tid % K4) * 4, rr = tid / K4 + q * RSTEP, r = r0 + rr;
-                if (r < rmax && rr < ROWS) {
-                    const float *p = src + (size_t)r * ld + k;
-                    if (k + 3 < kend) v = *reinterpret_cast<const float4 *>(p);
-                    else {
-                        if (k < kend) v.x = p[0];
-                        if (k + 1 < kend) v.y = p[1];
-                        if (k + 2 < kend) v.z = p[2];
-                    }
-                }
-            }
-            reg[q] = v;
-        }
-    }
-    // the same for a tile known to lie inside the operand (rows r0..r0+ROWS-1 < rmax, k0..k0+GBK-1 < kend): no predicates
-    __device__ static __forceinline__ void load_full(const float *__restrict__ src, int ld, int r0, int k0, int tid,
-                                                     float4 (&reg)[4]) {
-#pragma unroll
-        for (int q = 0; q < REPS; q++) {
-            if (!TRANS) {
-                constexpr int R4 = ROWS / 4, KSTEP = NT / R4;
-                const int r = r0 + (tid % R4) * 4, kk = tid / R4 + q * KSTEP;
-                if (REPS * KSTEP == GBK || kk < GBK) reg[q] = *reinterpret_cast<const float4 *>(src + (size_t)(k0 + kk) * ld + r);
-            } else {
-                constexpr int RSTEP = NT / K4;
-                const int k = k0 + (tid % K4) * 4, rr = tid / K4 + q * RSTEP;
-                if (REPS * RSTEP == ROWS || rr < ROWS) reg[q] = *reinterpret_cast<const float4 *>(src + (size_t)(r0 + rr) * ld + k);
-            }
-        }
-    }
-    __device__ static __forceinline__ void store(float *lds, int tid, const float4 (&reg)[4]) {
-#pragma unroll
-        for (int q = 0; q < REPS; q++) {
-            if (!TRANS) {
-                constexpr int R4 = ROWS / 4, KSTEP = NT / R4;
-                const int r = (tid % R4) * 4, k = tid / R4 + q * KSTEP;
-                if (k < GBK) *reinterpret_cast<float4 *>(lds + k * LD + r) = reg[q];
-            } else {
-                constexpr int RSTEP = NT / K4;
-                const int k = (tid % K4) * 4, r = tid / K4 + q * RSTEP;
-                if (r < ROWS) {
-                    lds[(k + 0) * LD + r] = reg[q].x;
-                    lds[(k + 1) * LD + r] = reg[q].y;
-                    lds[(k + 2) * LD + r] = reg[q].z;
-                    lds[(k + 3) * LD + r] = reg[q].w;
-                }
-            }
-        }
-    }
-};
-
-// MW = 2: 128-row tile, 4 waves; MW = 4: 256-row tile, 8 waves (more FLOP per byte pulled through L2: the
-// K = T products re-read their operands once per tile column/row, and were bandwidth- not MFMA-bound).
-template <bool TA, bool TB, int NI, int MW>
-__global__ __launch_bounds__(128 * MW) void k_gemm(int M, int Nn, int K, const float *__restrict__ A, int lda,
-                                                   const float *__restrict__ Bm, int ldb, float *__restrict__ C, int ldc,
-                                                   int kchunk, size_t slab_stride, int z0) {
-    constexpr int BM = 64 * MW, GBN = 64 * NI, NT = 128 * MW;
-    using TileA = GemmTile<TA, BM, NT>;
-    using TileB = GemmTile<!TB, GBN, NT>;
-    // two LDS stages: tile k+1 is written while tile k is being read, one barrier per k-tile
-    extern __shared__ __attribute__((aligned(16))) float gemm_lds[]; // As[2][GBK*LDA] | Bs[2][GBK*LDB] (up to 100 KB)
-    float(*As)[GBK * TileA::LD] = reinterpret_cast<float(*)[GBK * TileA::LD]>(gemm_lds);
-    float(*Bs)[GBK * TileB::LD] = reinterpret_cast<float(*)[GBK * TileB::LD]>(gemm_lds + 2 * GBK * TileA::LD);
-    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int wm = w % MW, wn = w / MW;
-    // XCD-aware block order (speed only): consecutive block ids are dealt round-robin over the 8 XCDs, each
-    // with its own L2.  Give every XCD one contiguous range of (k-slice, column tile, row tile): with 8
-    // K-slices an XCD then streams only its own slice of both operands instead of all of them.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    {
-        const int total = gridDim.x * gridDim.y * gridDim.z;
-        if ((total & 7) == 0) {
-            const int lin = bx + gridDim.x * (by + gridDim.y * bz);
-            const int nl = (lin & 7) * (total >> 3) + (lin >> 3);
-            bx = nl % gridDim.x;
-            by = (nl / gridDim.x) % gridDim.y;
-            bz = nl / (gridDim.x * gridDim.y);
-        }
-    }
-    const int m0 = bx * BM, n0 = by * GBN;
-    const int kbeg = (bz + z0) * kchunk;
-    const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
-    C += (size_t)(bz + z0) * slab_stride;
-
-    f32x16 acc[2][NI];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < NI; b++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
-
-    float4 ra[4], rb[4];
-    // op(A): TA=false -> A is M x K, m contiguous (direct); TA=true -> A stored K x M, k contiguous
-    // op(B): TB=true  -> B stored Nn x K, n contiguous (direct); TB=false -> B is K x Nn, k contiguous
-    //
-    // Pipeline, one barrier per k-tile: while the MFMAs of tile k run on fragments already in registers, the fragments
-    // of tile k+1 are read from the other LDS stage into a second register set and the global loads of tile k+2 are in
-    // flight; tile k+2 is stored over tile k's stage (whose fragments were read an iteration ago) before the barrier.
-    // (Reading a tile's fragments right after the barrier that publishes it leaves the matrix pipe idle while all
-    // eight waves queue on the LDS: 64 KB per k-tile, ~500 cycles, plus the read latency.)
-    const int ntiles = (kend - kbeg + GBK - 1) / GBK;
-    const bool inside_mn = m0 + BM <= M && n0 + GBN <= Nn;
-    auto read_frags = [&](int stage, float (&af)[GBK / 2][2], float (&bf)[GBK / 2][NI]) {
-        const float *Ac = As[stage], *Bc = Bs[stage];
-#pragma unroll
-        for (int s2 = 0; s2 < GBK / 2; s2++) {
-            const int k = 2 * s2 + (l >> 5);
-            af[s2][0] = Ac[k * TileA::LD + wm * 64 + (l & 31)];
-            af[s2][1] = Ac[k * TileA::LD + wm * 64 + 32 + (l & 31)];
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) bf[s2][ni] = Bc[k * TileB::LD + wn * 32 * NI + ni * 32 + (l & 31)];
-        }
-    };
-    auto tile_step = [&](int kt, float (&afc)[GBK / 2][2], float (&bfc)[GBK / 2][NI], float (&afn)[GBK / 2][2],
-                         float (&bfn)[GBK / 2][NI]) {
-        const bool more2 = kt + 2 < ntiles, more1 = kt + 1 < ntiles;
-        if (more2) {
-            const int kk = kbeg + (kt + 2) * GBK;
-            if (inside_mn && kk + GBK <= kend) { // interior tile: predicate-free loads (a few instructions, not a hundred)
-                TileA::load_full(A, lda, m0, kk, tid, ra);
-                TileB::load_full(Bm, ldb, n0, kk, tid, rb);
-            } else {
-                TileA::load(A, lda, m0, M, kk, kend, tid, ra);
-                TileB::load(Bm, ldb, n0, Nn, kk, kend, tid, rb);
-            }
-        }
-        if (more1) read_frags((kt + 1) & 1, afn, bfn);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s2 = 0; s2 < GBK / 2; s2++)
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                for (int ni = 0; ni < NI; ni++)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfc[s2][ni], afc[s2][mi], acc[mi][ni], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more2) {
-            TileA::store(As[kt & 1], tid, ra);
-            TileB::store(Bs[kt & 1], tid, rb);
-        }
-        __syncthreads();
-    };
-    TileA::load(A, lda, m0, M, kbeg, kend, tid, ra);
-    TileB::load(Bm, ldb, n0, Nn, kbeg, kend, tid, rb);
-    TileA::store(As[0], tid, ra);
-    TileB::store(Bs[0], tid, rb);
-    if (ntiles > 1) {
-        TileA::load(A, lda, m0, M, kbeg + GBK, kend, tid, ra);
-        TileB::load(Bm, ldb, n0, Nn, kbeg + GBK, kend, tid, rb);
-        TileA::store(As[1], tid, ra);
-        TileB::store(Bs[1], tid, rb);
-    }
-    __syncthreads();
-    float af0[GBK / 2][2], bf0[GBK / 2][NI], af1[GBK / 2][2], bf1[GBK / 2][NI];
-    read_frags(0, af0, bf0);
-    __syncthreads(); // tile_step(0) stores tile 2 over stage 0: every wave's stage-0 fragments must be in registers first
-    for (int kt = 0; kt < ntiles; kt += 2) {
-        tile_step(kt, af0, bf0, af1, bf1);
-        if (kt + 1 < ntiles) tile_step(kt + 1, af1, bf1, af0, bf0);
-    }
-    // D[row][col] of the swapped product = C[m = col][n = row]
-#pragma unroll
-    for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-        for (int ni = 0; ni < NI; ni++) {
-            const int m = m0 + wm * 64 + mi * 32 + (l & 31);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int n = n0 + wn * 32 * NI + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-                if (m < M && n < Nn) C[(size_t)n * ldc + m] = acc[mi][ni][r];
-            }
-        }
-}
-
 __global__ __launch_bounds__(256) void k_gemm_reduce(const float *__restrict__ slabs, int splits, int M, int Nn,
                                                      float *__restrict__ C, int ldc, size_t slab_stride) {
     const size_t total = (size_t)M * Nn;
@@ -569,54 +359,6 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const float *__restrict__ s
     }
 }
 
-// Tile shape.  Columns: 128 per workgroup unless that leaves most of the 256 CUs idle.  Rows: 256 (8 waves)
-// for the big long-K products, whose cost is the operand bytes re-read per tile; 128 otherwise.
-struct GemmShape {
-    int bm, bn;
-};
-static GemmShape gemm_pick_shape(int M, int Nn, int K) {
-    const int tiles128 = ((M + 127) / 128) * ((Nn + 127) / 128);
-    GemmShape s;
-    if (K >= 2048) s.bn = tiles128 >= 32 ? 128 : 64;
-    else s.bn = tiles128 >= 192 ? 128 : 64;
-    s.bm = (K >= 2048 && s.bn == 128 && M >= 1024) ? 256 : 128;
-    return s;
-}
-int gemm_pick_splits(int M, int Nn, int K) {
-    const GemmShape sh = gemm_pick_shape(M, Nn, K);
-    const int tiles = ((M + sh.bm - 1) / sh.bm) * ((Nn + sh.bn - 1) / sh.bn);
-    int splits = 1;
-    // aim for >= ~512 workgroups (256 of the 8-wave ones), keep >= 8 k-tiles per split
-    const int want = sh.bm == 256 ? 256 : 512;
-    while (tiles * splits < want && K / (splits * 2) >= 8 * GBK) splits *= 2;
-    return splits;
-}
-
-static void gemm_launch(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb,
-                        float *out, int ldo, int kchunk, size_t stride, int z0, int nz, hipStream_t st) {
-    const GemmShape sh = gemm_pick_shape(M, Nn, K);
-    dim3 grid((M + sh.bm - 1) / sh.bm, (Nn + sh.bn - 1) / sh.bn, nz);
-#define GEMM_LAUNCH(ta, tb, ni, mw)                                                                                    \
-    do {                                                                                                               \
-        const size_t lds = sizeof(float) * 2 * GBK * ((64 * mw + 4) + (64 * ni + 4));                                  \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm<ta, tb, ni, mw>),                              \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-        hipLaunchKernelGGL((k_gemm<ta, tb, ni, mw>), grid, dim3(128 * mw), lds, st, M, Nn, K, A, lda, B, ldb, out, ldo, \
-                           kchunk, stride, z0);                                                                        \
-    } while (0)
-#define GEMM_NI(ta, tb)                                  \
-    do {                                                 \
-        if (sh.bm == 256) GEMM_LAUNCH(ta, tb, 2, 4);     \
-        else if (sh.bn == 128) GEMM_LAUNCH(ta, tb, 2, 2); \
-        else GEMM_LAUNCH(ta, tb, 1, 2);                  \
-    } while (0)
-    if (!TA && !TB) GEMM_NI(false, false);
-    else if (TA && !TB) GEMM_NI(true, false);
-    else if (!TA && TB) GEMM_NI(false, true);
-    else GEMM_NI(true, true);
-#undef GEMM_NI
-#undef GEMM_LAUNCH
-}
 static void gemm_reduce_launch(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st,
                                size_t slab_stride = 0) {
     size_t total = (size_t)M * Nn;
@@ -624,30 +366,6 @@ static void gemm_reduce_launch(const float *slabs, int splits, int M, int Nn, fl
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_gemm_reduce, dim3(blocks), dim3(256), 0, st, slabs, splits, M, Nn, C, ldc,
                        slab_stride ? slab_stride : total);
-}
-
-void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
-          int splits, float *slabs, hipStream_t st) {
-    if (splits < 1) splits = 1;
-    int kchunk = (K + splits - 1) / splits;
-    kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
-    splits = (K + kchunk - 1) / kchunk;
-    float *out = splits > 1 ? slabs : C;
-    const int ldo = splits > 1 ? M : ldc;
-    const size_t stride = splits > 1 ? (size_t)M * Nn : 0;
-    gemm_launch(TA, TB, M, Nn, K, A, lda, B, ldb, out, ldo, kchunk, stride, 0, splits, st);
-    if (splits > 1) gemm_reduce_launch(slabs, splits, M, Nn, C, ldc, st);
-}
-
-// the split-K product without its fold: `splits` slabs of M*Nn floats (gemm_pick_splits's count; slab z covers k-chunk z).
-// Returns the number of slabs written (the K chunking can need fewer than asked for).
-int gemm_slabs(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *slabs, int splits,
-               hipStream_t st) {
-    int kchunk = (K + splits - 1) / splits;
-    kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
-    splits = (K + kchunk - 1) / kchunk;
-    gemm_launch(TA, TB, M, Nn, K, A, lda, B, ldb, slabs, M, kchunk, (size_t)M * Nn, 0, splits, st);
-    return splits;
 }
 void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc, hipStream_t st, size_t slab_stride) {
     gemm_reduce_launch(slabs, splits, M, Nn, C, ldc, st, slab_stride);

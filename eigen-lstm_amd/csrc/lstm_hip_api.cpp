@@ -50,39 +50,6 @@ const char *const kKernelNames[K_COUNT] = {
     "pack_U", "fwd_step", "gemm_Y", "softmax_loss_dy", "loss_reduce", "gemm_DHy", "bwd_step", "gemm_dWhy", "gemm_dU",
     "dW_db", "loss_dby", "adagrad", "slide", "allreduce", "fwd_persistent", "bwd_persistent"};
 
-// ---- rocBLAS for the two plain time-batched fp32 products (Y = Why*H and dU = DG*H^T), loaded with dlopen -----------------
-// These are library GEMMs in the plainest sense (column-major, no epilogue), and rocBLAS's tuned kernels run them at
-// 138 TFLOP/s / 17.8 us against 113 TFLOP/s / 32 us for k_gemm (tools/probes/rocblas_dU_probe.cpp).  Atomics are
-// disallowed on the handle, which keeps its reductions deterministic (checked bit for bit by the same probe).  Without
-// the library, or with LSTM_HIP_GEMM=native, k_gemm serves them as before.
-struct Rocblas {
-    void *lib = nullptr;
-    int (*create)(void **) = nullptr;
-    int (*destroy)(void *) = nullptr;
-    int (*set_stream)(void *, hipStream_t) = nullptr;
-    int (*set_atomics)(void *, int) = nullptr;
-    int (*sgemm)(void *, int, int, int, int, int, const float *, const float *, int, const float *, int, const float *, float *,
-                 int) = nullptr;
-};
-Rocblas g_blas;
-bool load_rocblas() {
-    if (g_blas.lib) return true;
-    void *lib = dlopen("librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
-    if (!lib) lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-    if (!lib) return false;
-    Rocblas b;
-    b.create = (decltype(b.create))dlsym(lib, "rocblas_create_handle");
-    b.destroy = (decltype(b.destroy))dlsym(lib, "rocblas_destroy_handle");
-    b.set_stream = (decltype(b.set_stream))dlsym(lib, "rocblas_set_stream");
-    b.set_atomics = (decltype(b.set_atomics))dlsym(lib, "rocblas_set_atomics_mode");
-    b.sgemm = (decltype(b.sgemm))dlsym(lib, "rocblas_sgemm");
-    if (!b.create || !b.destroy || !b.set_stream || !b.set_atomics || !b.sgemm) return false;
-    b.lib = lib;
-    g_blas = b;
-    return true;
-}
-constexpr int ROCBLAS_OP_N = 111, ROCBLAS_OP_T = 112; // rocblas_operation_none / _transpose
-
 // ---- RCCL, loaded on first use so single-GPU users never touch it --------------------------
 struct UniqueId {
     char internal[LSTM_HIP_UNIQUE_ID_BYTES];
@@ -149,8 +116,6 @@ struct lstm_hip_ctx {
     float4 *Ubwd4 = nullptr; // weight image of the 4x4x1 backward form (kernels.hip, k_pack_U), when bwd_uses_m4
     float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel (fwd_uses_8col_form) or, fwd_cols4, of the two-half one
     int n_cus = 0;           // compute units of the device (grid choices)
-    void *blas = nullptr;    // rocBLAS handle on `st` (null: k_gemm serves the time-batched products)
-    bool blas_Y = false, blas_dU = false; // which of the two products go through it: whichever was faster at create
     bool side_stream = true; // LSTM_HIP_NO_SIDE_STREAM=1 (per handle): keep the whole window on one stream
     int bwd_halves = 0;      // 1: backward recurrence likewise (k_bwd_halves; LSTM_HIP_BWD_HALVES=1, unfused gradient sums)
     int fwd_cols4 = 0;       // 1: forward recurrence as two alternating 4-column halves per workgroup (k_fwd_persistent6)
@@ -265,12 +230,14 @@ int check_abort(lstm_hip_ctx *h) {
     return 0;
 }
 
-// reported loss: all S-1 steps in bits (R/lstm.cc:204-207) or the last step only in nats
-// (OV/lstm_eigen_class_CUDA/lstm.h:200-221); colloss holds -log2 p(target) per (step, column)
+// reported loss: all S-1 steps in bits (R/lstm.cc:204-207), or the last step only -- in nats
+// (OV/lstm_eigen_class_CUDA/lstm.h:200-221) or in bits (cuLSTM::calculate_loss, cu_lstm.h:203-215);
+// colloss holds -log2 p(target) per (step, column)
+bool loss_last_step(const lstm_hip_ctx *h) { return h->loss_mode != LSTM_HIP_LOSS_ALL_STEPS_BITS; }
 const float *loss_src(const lstm_hip_ctx *h) {
-    return h->loss_mode == LSTM_HIP_LOSS_LAST_STEP_NATS ? h->colloss + (size_t)(h->cfg.S - 2) * h->cfg.B : h->colloss;
+    return loss_last_step(h) ? h->colloss + (size_t)(h->cfg.S - 2) * h->cfg.B : h->colloss;
 }
-int loss_steps(const lstm_hip_ctx *h) { return h->loss_mode == LSTM_HIP_LOSS_LAST_STEP_NATS ? 1 : h->cfg.S - 1; }
+int loss_steps(const lstm_hip_ctx *h) { return loss_last_step(h) ? 1 : h->cfg.S - 1; }
 float loss_scale(const lstm_hip_ctx *h) { return h->loss_mode == LSTM_HIP_LOSS_LAST_STEP_NATS ? 0.693147180559945f : 1.0f; }
 
 int launch_fwd_recurrence(lstm_hip_ctx *h) {
@@ -331,13 +298,6 @@ int do_forward(lstm_hip_ctx *h) {
         }
         RUN(K_GEMM_Y, gemm_bf16(256, h->T, N, h->WhyT_b, N, h->Hb + (size_t)N * B, N, h->Y + (size_t)256 * B, 256, 1, nullptr,
                                 h->st));
-    } else
-    if (h->blas_Y) {
-        const float one = 1.0f, zero = 0.0f;
-        int rc = 0;
-        RUN(K_GEMM_Y, rc = g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_N, 256, h->T, N, &one, h->P + h->pl.Why, 256,
-                                        h->H + (size_t)N * B, N, &zero, h->Y + (size_t)256 * B, 256));
-        if (rc != 0) return fail(LSTM_HIP_EHIP, "rocblas_sgemm (Y): status %d", rc);
     } else
     RUN(K_GEMM_Y, gemm(false, false, 256, h->T, N, h->P + h->pl.Why, 256, h->H + (size_t)N * B, N,
                        h->Y + (size_t)256 * B, 256, 1, nullptr, h->st));
@@ -464,23 +424,21 @@ int do_backward(lstm_hip_ctx *h) {
         }
         if (rc != 0)
             return fail(LSTM_HIP_ERCCL, "ncclAllReduce (early ranges): %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
-        // With the dU product in two column halves (rocBLAS path), the first half's all-reduce also goes on st2, behind the
-        // early ranges and beside the second half's product; only the second half is left for `st`.
+        // With LSTM_HIP_DU_SPLIT=1 the dU product runs as two column halves and the first half's all-reduce also goes on st2,
+        // behind the early ranges and beside the second half's product; only the second half is left for `st`.  Off by
+        // default: two half-size products cost more than the whole one, about what hiding half of the dU all-reduce can
+        // win back (measured with a 1-rank communicator, tools/comm_overhead_probe.py); to be decided on a multi-GPU node.
+        // The switch is read once per process and the path depends on nothing else, so every rank of a job (same
+        // environment) posts the same sequence of collectives.
         h->dU_reduced = 0;
-        // Off by default: the two half-size products cost 17.5 us more than the whole one (measured with a 1-rank
-        // communicator, tools/comm_overhead_probe.py), about what hiding half of the dU all-reduce can win back; to be
-        // decided on a real multi-GPU node (LSTM_HIP_DU_SPLIT=1).
         static const bool du_split = getenv("LSTM_HIP_DU_SPLIT") && atoi(getenv("LSTM_HIP_DU_SPLIT")) != 0;
-        if (h->blas_dU && !h->bf16 && du_split) {
-            const float one = 1.0f, zero = 0.0f;
-            const int n1 = N / 2;
-            int brc = g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_T, G4, n1, T, &one, h->DG + (size_t)G4 * B, G4, h->H, N, &zero,
-                                   h->dP + h->pl.U, G4);
-            if (brc != 0) return fail(LSTM_HIP_EHIP, "rocblas_sgemm (dU, first half): status %d", brc);
+        if (!h->bf16 && du_split) {
+            int n1 = (N / 2) / 64 * 64; // whole 64-column tiles in the first half
+            if (n1 == 0) n1 = N / 2;
+            gemm(false, true, G4, n1, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->dP + h->pl.U, G4, h->splits_dU, h->slabs_dU, h->st);
             HIP_TRY(hipEventRecord(h->ev_mid, h->st));
-            brc = g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_T, G4, N - n1, T, &one, h->DG + (size_t)G4 * B, G4, h->H + n1, N,
-                               &zero, h->dP + h->pl.U + (size_t)G4 * n1, G4);
-            if (brc != 0) return fail(LSTM_HIP_EHIP, "rocblas_sgemm (dU, second half): status %d", brc);
+            gemm(false, true, G4, N - n1, T, h->DG + (size_t)G4 * B, G4, h->H + n1, N, h->dP + h->pl.U + (size_t)G4 * n1, G4,
+                 h->splits_dU, h->slabs_dU, h->st);
             HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_mid, 0));
             h->dU_reduced = (size_t)G4 * n1;
             rc = g_rccl.AllReduce(h->dP + h->pl.U, h->dP + h->pl.U, h->dU_reduced, 7, 0, h->comm, h->st2);
@@ -498,13 +456,6 @@ int do_backward(lstm_hip_ctx *h) {
         RUN(K_GEMM_DU, (transpose_pack_bf16(h->DG + (size_t)G4 * B, T, G4, G4, h->DGt_b, h->Tpad, h->st),
                         gemm_bf16(G4, N, h->Tpad, h->DGt_b, h->Tpad, h->Ht_b, h->SBpad, h->dP + h->pl.U, G4, h->splits_dU,
                                   h->slabs_dU, h->st)));
-    } else if (h->blas_dU) {
-        const float one = 1.0f, zero = 0.0f;
-        int rc = 0;
-        h->n_slabs_dU = 0; // straight into the gradient block
-        RUN(K_GEMM_DU, rc = g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_T, G4, N, T, &one, h->DG + (size_t)G4 * B, G4, h->H, N,
-                                         &zero, h->dP + h->pl.U, G4));
-        if (rc != 0) return fail(LSTM_HIP_EHIP, "rocblas_sgemm (dU): status %d", rc);
     } else if (defer_fold && h->splits_dU > 1)
         RUN(K_GEMM_DU, h->n_slabs_dU = gemm_slabs(false, true, G4, N, T, h->DG + (size_t)G4 * B, G4, h->H, N, h->slabs_dU,
                                                    h->splits_dU, h->st));
@@ -650,8 +601,8 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     ALLOC(h->dcnext, N * B);
     ALLOC(h->colloss, B * S);
     ALLOC(h->dby_part, (size_t)256 * softmax_parts(h->T));
-    h->splits_dWhy = gemm_pick_splits(256, (int)N, h->T);
-    h->splits_dU = gemm_pick_splits((int)G4, (int)N, h->T);
+    h->splits_dWhy = gemm_pick_splits(false, true, 256, (int)N, h->T, prop.multiProcessorCount);
+    h->splits_dU = gemm_pick_splits(false, true, (int)G4, (int)N, h->T, prop.multiProcessorCount);
     if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) {
         h->Tpad = (h->T + 63) / 64 * 64;
         h->SBpad = ((int)B + h->Tpad + 63) / 64 * 64;
@@ -726,79 +677,6 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
     if (h->persistent && (cfg->flags & LSTM_HIP_DEBUG_STAMPS) && cfg->N == 512 && h->Hx && h->Ubwd4) ALLOC(h->stamps, 4 * S * 16);
-    const char *gsel = getenv("LSTM_HIP_GEMM"); // "native": k_gemm (read per handle)
-    if (!h->bf16 && !(gsel && gsel[0] == 'n') && load_rocblas()) {
-        if (g_blas.create(&h->blas) != 0) h->blas = nullptr;
-        if (h->blas && (g_blas.set_stream(h->blas, h->st) != 0 || g_blas.set_atomics(h->blas, 0 /* not allowed */) != 0)) {
-            (void)g_blas.destroy(h->blas);
-            h->blas = nullptr;
-        }
-        if (h->blas) {
-            // First calls load and pick the kernels (tens of ms): here, not inside somebody's first window.  Then each
-            // product goes to whichever of the two implementations is faster for this shape on this device (rocBLAS wins
-            // both at the headline shape; k_gemm keeps e.g. Y at hidden 1024 with 12 672 columns, 120 against 255 us).
-            const float one = 1.0f, zero = 0.0f;
-            auto blas_Y = [&]() {
-                (void)g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_N, 256, h->T, (int)N, &one, h->P + h->pl.Why, 256, h->H + N * B,
-                                   (int)N, &zero, h->Y + (size_t)256 * B, 256);
-            };
-            auto own_Y = [&]() {
-                gemm(false, false, 256, h->T, (int)N, h->P + h->pl.Why, 256, h->H + N * B, (int)N, h->Y + (size_t)256 * B, 256, 1,
-                     nullptr, h->st);
-            };
-            auto blas_dU = [&]() {
-                (void)g_blas.sgemm(h->blas, ROCBLAS_OP_N, ROCBLAS_OP_T, (int)G4, (int)N, h->T, &one, h->DG + G4 * B, (int)G4, h->H,
-                                   (int)N, &zero, h->dP + h->pl.U, (int)G4);
-            };
-            auto own_dU = [&]() {
-                if (h->splits_dU > 1)
-                    (void)gemm_slabs(false, true, (int)G4, (int)N, h->T, h->DG + G4 * B, (int)G4, h->H, (int)N, h->slabs_dU,
-                                     h->splits_dU, h->st);
-                else
-                    gemm(false, true, (int)G4, (int)N, h->T, h->DG + G4 * B, (int)G4, h->H, (int)N, h->dP + h->pl.U, (int)G4, 1,
-                         nullptr, h->st);
-            };
-            auto best_ms = [&](auto &&fn, float *out) -> int { // best of three, after two warm-up calls
-                fn();
-                fn();
-                float best = 1e30f;
-                for (int i = 0; i < 3; i++) {
-                    float ms = 0.0f;
-                    HIP_TRY(hipEventRecord(h->evt0, h->st));
-                    fn();
-                    HIP_TRY(hipEventRecord(h->evt1, h->st));
-                    HIP_TRY(hipEventSynchronize(h->evt1));
-                    HIP_TRY(hipEventElapsedTime(&ms, h->evt0, h->evt1));
-                    best = ms < best ? ms : best;
-                }
-                *out = best;
-                return 0;
-            };
-            // One decision per shape and process: handles of the same shape must compute alike (tests compare two of them bit
-            // for bit), and a timing that is close could otherwise fall either way.
-            static std::mutex choice_mu;
-            static std::map<std::tuple<int, int, int>, std::pair<bool, bool>> choice;
-            const std::tuple<int, int, int> key((int)N, h->T, h->cfg.device);
-            std::lock_guard<std::mutex> lk(choice_mu);
-            auto it = choice.find(key);
-            if (it == choice.end()) {
-                float tb = 0.f, to = 0.f;
-                int rc_ = 0;
-                if ((rc_ = best_ms(blas_Y, &tb)) || (rc_ = best_ms(own_Y, &to))) return rc_;
-                const bool by_ = tb < 0.9f * to; // a clear win only
-                if ((rc_ = best_ms(blas_dU, &tb)) || (rc_ = best_ms(own_dU, &to))) return rc_;
-                it = choice.emplace(key, std::make_pair(by_, tb < 0.9f * to)).first;
-            } else { // still make the first calls on this handle (kernel selection, workspace)
-                blas_Y();
-                blas_dU();
-            }
-            h->blas_Y = it->second.first;
-            h->blas_dU = it->second.second;
-            HIP_TRY(hipStreamSynchronize(h->st));
-            HIP_TRY(hipMemsetAsync(h->dP, 0, sizeof(float) * h->pl.total, h->st));
-            HIP_TRY(hipMemsetAsync(h->Y, 0, sizeof(float) * 256 * S * B, h->st));
-        }
-    }
     HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
@@ -817,7 +695,6 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->h_losses) (void)hipHostFree(h->h_losses);
-    if (h->blas) (void)g_blas.destroy(h->blas);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->evt0) (void)hipEventDestroy(h->evt0);
@@ -1045,7 +922,7 @@ int lstm_hip_set_global_batch(lstm_hip_t *h, int32_t global_B) {
 }
 
 int lstm_hip_set_loss_mode(lstm_hip_t *h, int32_t mode) {
-    if (!h || (mode != LSTM_HIP_LOSS_ALL_STEPS_BITS && mode != LSTM_HIP_LOSS_LAST_STEP_NATS))
+    if (!h || (mode != LSTM_HIP_LOSS_ALL_STEPS_BITS && mode != LSTM_HIP_LOSS_LAST_STEP_NATS && mode != LSTM_HIP_LOSS_LAST_STEP_BITS))
         return fail(LSTM_HIP_EINVAL, "set_loss_mode: unknown mode %d", mode);
     h->loss_mode = mode;
     return 0;

@@ -61,6 +61,7 @@ struct Options {
     unsigned flags = 0;
     bool quiet = false;
     bool last_step_loss = false; // report forward_loss of OV/lstm_eigen_class_CUDA/lstm.h:200-221 (last step, nats)
+    bool last_step_bits = false; // ... or cuLSTM::calculate_loss, cu_lstm.h:203-215 (last step, bits)
 };
 
 [[noreturn]] void die(const std::string &m) {
@@ -202,11 +203,12 @@ Options parse(int argc, char **argv) {
         else if (a == "--fast-math") o.flags |= LSTM_HIP_FAST_MATH;
         else if (a == "--step-kernels") o.flags |= LSTM_HIP_STEP_KERNELS;
         else if (a == "--last-step-loss") o.last_step_loss = true;
+        else if (a == "--last-step-loss-bits") o.last_step_bits = true;
         else if (a == "--quiet") o.quiet = true;
         else if (a == "-h" || a == "--help") {
             printf("usage: lstm <text file> <hidden> <seq> <batch> <lr> [--epochs E --seed K --gpus G --windows W --sample C\n"
                    "            --lr-warmup-windows X --save PREFIX --load PREFIX --eval-file F --stride K --forget-bias V\n"
-                   "            --test-percent F --test-every SEC --log PREFIX --last-step-loss --fast-math --step-kernels --quiet]\n");
+                   "            --test-percent F --test-every SEC --log PREFIX --last-step-loss --last-step-loss-bits --fast-math --step-kernels --quiet]\n");
             exit(0);
         } else if (a.rfind("--", 0) == 0) die("unknown option " + a);
         else pos.push_back(a);
@@ -285,6 +287,7 @@ int run_rank(const Options &o, int rank, int up, int down) {
     CK(lstm_hip_set_cursors(h, pos.data()));
     CK(lstm_hip_reset_window(h));
     if (o.last_step_loss) CK(lstm_hip_set_loss_mode(h, LSTM_HIP_LOSS_LAST_STEP_NATS));
+    if (o.last_step_bits) CK(lstm_hip_set_loss_mode(h, LSTM_HIP_LOSS_LAST_STEP_BITS));
     if (o.stride > 1) CK(lstm_hip_set_stride(h, o.stride, o.stride - 1)); // segment variant: carry from column seg-1
 
     const double flops_per_iteration = count_flops(M, N, S, o.B);

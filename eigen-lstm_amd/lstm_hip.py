@@ -22,7 +22,7 @@ STEP_KERNELS = 4
 DEBUG_STAMPS = 16
 NO_FUSED_GRADS = 64
 BF16_RECURRENCE = 128
-LOSS_ALL_STEPS_BITS, LOSS_LAST_STEP_NATS = 0, 1
+LOSS_ALL_STEPS_BITS, LOSS_LAST_STEP_NATS, LOSS_LAST_STEP_BITS = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 VOCAB = 256
 
@@ -213,7 +213,8 @@ class Lstm:
         _chk(self.lib.lstm_hip_set_global_batch(self._h, gb))
 
     def set_loss_mode(self, mode):
-        """LOSS_ALL_STEPS_BITS (R/lstm.cc:204-207) or LOSS_LAST_STEP_NATS (OV/lstm_eigen_class_CUDA/lstm.h:200-221)."""
+        """LOSS_ALL_STEPS_BITS (R/lstm.cc:204-207), LOSS_LAST_STEP_NATS (OV/lstm_eigen_class_CUDA/lstm.h:200-221) or
+        LOSS_LAST_STEP_BITS (cuLSTM::calculate_loss, OV/lstm_eigen_class_CUDA/cu_lstm.h:203-215)."""
         _chk(self.lib.lstm_hip_set_loss_mode(self._h, mode))
 
     # ---- device-resident loop ------------------------------------------------------------------

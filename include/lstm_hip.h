@@ -140,11 +140,16 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
 int lstm_hip_set_stride(lstm_hip_t *h, int32_t stride, int32_t carry_col);
 /* global batch the loss is divided by (defaults to B; set by the host when streams are sharded) */
 int lstm_hip_set_global_batch(lstm_hip_t *h, int32_t global_B);
-/* what lstm_hip_loss / train_windows report: the sum over all S-1 steps in bits (R/lstm.cc:204-207, the default) or the
- * last step only in nats (forward_loss of OV/lstm_eigen_class_CUDA/lstm.h:200-221).  The gradients do not change: that
- * variant's backward still uses dy of every step (lstm.h:299-302). */
+/* what lstm_hip_loss / train_windows report:
+ *   ALL_STEPS_BITS  the sum over all S-1 steps of -log2 p(target) / B (R/lstm.cc:204-207; the default)
+ *   LAST_STEP_NATS  step S-1 only, natural log (the CPU class of that variant: forward_loss,
+ *                   OV/lstm_eigen_class_CUDA/lstm.h:200-221)
+ *   LAST_STEP_BITS  step S-1 only, -log2, / B: exactly cuLSTM::calculate_loss, the boundary member lstm_hip_loss replaces
+ *                   (OV/lstm_eigen_class_CUDA/cu_lstm.h:203-215 with kernel_elementwise_neglog, cu_kernels.cu:211-225)
+ * The gradients do not change: that variant's backward still uses dy of every step (lstm.h:299-302, cu_lstm.h:216-300). */
 #define LSTM_HIP_LOSS_ALL_STEPS_BITS 0
 #define LSTM_HIP_LOSS_LAST_STEP_NATS 1
+#define LSTM_HIP_LOSS_LAST_STEP_BITS 2
 int lstm_hip_set_loss_mode(lstm_hip_t *h, int32_t mode);
 
 /* ---- held-out evaluator and sampler on the device (OV/lstm_eigen_class_CUDA/lstm.cc:661-720,

@@ -61,6 +61,13 @@
  * (W gather, biases, gates, output layer, every weight gradient, Adagrad on fp32 master weights) is unchanged. */
 static int g_bf16_recurrence = 0;
 void ref_set_bf16_recurrence(int on) { g_bf16_recurrence = on; }
+/* Control for the trajectory tests (tests/trajectory_util.py): every contraction of the window runs over its index in
+ * DESCENDING order.  The reference leaves the summation order of its products to Eigen / BLAS, so this is as
+ * correct an implementation of OV/lstm_eigen_opt/lstm.cc:186-318 as the ascending one; how far the two drift apart in a
+ * free-running training loop is the yardstick for a GPU implementation whose products sum in yet another order. */
+static int g_desc_sums = 0;
+void ref_set_descending_sums(int on) { g_desc_sums = on; }
+#define KI(k, n) (g_desc_sums ? (n) - 1 - (k) : (k))
 /* ... and of the four time-batched products as well (the complete "bf16 MFMA path" of configs[4]): y = Why*h, dWhy = dy*h^T,
  * Why^T*dy and dU = dg*h_prev^T take bf16-rounded operands (the SAME rounded h, dg as the recurrence; dy and Why rounded
  * once), accumulate in fp32.  Biases, dW/db/dby (sums, no products), the elementwise math and Adagrad stay fp32. */
@@ -239,7 +246,8 @@ void FN(ref_forward)(int N, int M, int S, int B, const REAL *P, const int32_t *x
              * products in ascending k, so the rounding sequence is that of a plain dot product */
             int xk = xi[t * B + b];
             for (int r = 0; r < G; r++) gc[r] = 0;
-            for (int k = 0; k < N; k++) {
+            for (int k0 = 0; k0 < N; k0++) {
+                const int k = KI(k0, N);
                 const REAL hk = Ub ? (REAL)bf16_rne((float)hp[(size_t)b * N + k]) : hp[(size_t)b * N + k];
                 const REAL *Uk = Urec + (size_t)k * G;
                 for (int r = 0; r < G; r++) gc[r] += Uk[r] * hk;
@@ -261,7 +269,8 @@ void FN(ref_forward)(int N, int M, int S, int B, const REAL *P, const int32_t *x
             REAL *pc = pt + (size_t)b * M;
             REAL sum = 0;
             for (int m = 0; m < M; m++) pc[m] = 0;
-            for (int k = 0; k < N; k++) {
+            for (int k0 = 0; k0 < N; k0++) {
+                const int k = KI(k0, N);
                 const REAL hk = Whyb ? (REAL)bf16_rne((float)ht[(size_t)b * N + k]) : ht[(size_t)b * N + k];
                 const REAL *Wk = Whyf + (size_t)k * M;
                 for (int m = 0; m < M; m++) pc[m] += Wk[m] * hk;
@@ -340,7 +349,8 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
         for (int k = 0; k < N; k++) {
             REAL tmp[256];
             for (int m = 0; m < M; m++) tmp[m] = 0;
-            for (int b = 0; b < B; b++) {
+            for (int b0 = 0; b0 < B; b0++) {
+                const int b = KI(b0, B);
                 const REAL hk = htp[(size_t)b * N + k];
                 for (int m = 0; m < M; m++) tmp[m] += dyp[(size_t)b * M + m] * hk;
             }
@@ -348,7 +358,7 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
         }
         for (int m = 0; m < M; m++) {
             REAL acc = 0;
-            for (int b = 0; b < B; b++) acc += dy[(size_t)b * M + m];
+            for (int b0 = 0; b0 < B; b0++) acc += dy[(size_t)KI(b0, B) * M + m];
             d.by[m] += acc;
         }
         /* dh = Why^T * dy + dhnext   (opt:273) */
@@ -356,7 +366,10 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
         for (int b = 0; b < B; b++)
             for (int k = 0; k < N; k++) {
                 REAL acc = 0;
-                for (int m = 0; m < M; m++) acc += Whyf[(size_t)k * M + m] * dyp[(size_t)b * M + m];
+                for (int m0 = 0; m0 < M; m0++) {
+                    const int m = KI(m0, M);
+                    acc += Whyf[(size_t)k * M + m] * dyp[(size_t)b * M + m];
+                }
                 dh[(size_t)b * N + k] = acc + dhnext[(size_t)b * N + k];
             }
         for (int b = 0; b < B; b++) {
@@ -384,7 +397,8 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
         for (int k = 0; k < N; k++) {
             REAL *tmp = utmp + (size_t)k * G; /* per-k scratch row (thread-private under OpenMP) */
             for (int r = 0; r < G; r++) tmp[r] = 0;
-            for (int b = 0; b < B; b++) {
+            for (int b0 = 0; b0 < B; b0++) {
+                const int b = KI(b0, B);
                 const REAL hk = hpp[(size_t)b * N + k];
                 const REAL *dgc2 = dgprod + (size_t)b * G;
                 for (int r = 0; r < G; r++) tmp[r] += dgc2[r] * hk;
@@ -398,7 +412,7 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
         }
         for (int r = 0; r < G; r++) {
             REAL acc = 0;
-            for (int b = 0; b < B; b++) acc += dg[(size_t)b * G + r];
+            for (int b0 = 0; b0 < B; b0++) acc += dg[(size_t)KI(b0, B) * G + r];
             d.b[r] += acc;
         }
         /* dhnext = U^T * dg ; dcnext = dc .* f   (opt:302-303) */
@@ -407,7 +421,10 @@ void FN(ref_backward)(int N, int M, int S, int B, const REAL *P, const int32_t *
         for (int b = 0; b < B; b++)
             for (int k = 0; k < N; k++) {
                 REAL acc = 0;
-                for (int r = 0; r < G; r++) acc += Urec[(size_t)k * G + r] * dgrec[(size_t)b * G + r];
+                for (int r0 = 0; r0 < G; r0++) {
+                    const int r = KI(r0, G);
+                    acc += Urec[(size_t)k * G + r] * dgrec[(size_t)b * G + r];
+                }
                 dhnext[(size_t)b * N + k] = acc;
             }
         for (int b = 0; b < B; b++)

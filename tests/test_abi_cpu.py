@@ -74,6 +74,23 @@ def test_host_rng_and_cursors_match_the_oracle_spec(oracle32):
     assert [int(v) for v in tr.ti[6]] == [int(text[int(p) + 2]) for p in pos]
 
 
+def test_forget_bias_init_variant():
+    """init_params(forget_bias=1): b[2N:3N] = 1 (OV/lstm_eigen_class_batch/lstm.cc:81; gate rows are i, o, f, u), every other
+    value and the random stream exactly as with the root file's b = 0."""
+    import lstm_hip
+    N = 48
+    P0 = lstm_hip.init_params(lstm_hip.MT19937Normal(9), N)
+    g1 = lstm_hip.MT19937Normal(9)
+    P1 = lstm_hip.init_params(g1, N, forget_bias=1.0)
+    off_b = 4 * N * 256 + 4 * N * N
+    assert np.all(P1[off_b + 2 * N:off_b + 3 * N] == 1.0) and not P0[off_b:off_b + 4 * N].any()
+    P1[off_b + 2 * N:off_b + 3 * N] = 0.0
+    assert np.array_equal(P0, P1)
+    g0 = lstm_hip.MT19937Normal(9)
+    lstm_hip.init_params(g0, N)
+    assert np.array_equal(g0.randn(4, 2, 0.0, 1.0), g1.randn(4, 2, 0.0, 1.0))    # the stream is where it would have been
+
+
 def _reference_reader_rows(path):
     """The row count the reference's readMatrix would reach (OV/lstm_eigen_class_CUDA/io.h:36-74): it calls getline
     until eof is set, counting every line -- including the empty one a trailing newline produces."""

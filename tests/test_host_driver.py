@@ -55,6 +55,35 @@ def test_cli_epoch_report_matches_oracle(tmp_path, oracle32):
     assert abs(float(m2.group(1)) - oracle32.eval_bits(N, 256, P, text)) <= 1e-3
 
 
+def test_cli_forget_bias_variant(tmp_path, oracle32):
+    """--forget-bias 1: the later variants' b[2N:3N] = 1 at initialisation (OV/lstm_eigen_class_batch/lstm.cc:81), everything
+    else as the root file; the epoch report follows the oracle's trainer started from the same parameters."""
+    N, S, B, lr, windows = 32, 8, 4, 0.01, 40
+    text = _text(seed=13)
+    f = tmp_path / "corpus.txt"
+    text.tofile(f)
+    out = subprocess.run([LSTM, str(f), str(N), str(S), str(B), str(lr), "--epochs", "1", "--windows", str(windows), "--seed", "5",
+                          "--sample", "0", "--forget-bias", "1", "--save", str(tmp_path / "fb")],
+                         capture_output=True, text=True, errors="replace", timeout=120)
+    assert out.returncode == 0, out.stderr
+    m = re.search(r"avg loss = ([\d.]+) bits/char", out.stdout)
+    assert m, out.stdout
+    tr = oracle32.trainer(text, N, S, B, lr=lr, seed=5)
+    off_b = 4 * N * 256 + 4 * N * N
+    assert not tr.params[off_b:off_b + 4 * N].any()
+    tr.params[off_b + 2 * N:off_b + 3 * N] = 1.0                                   # the f-gate rows (gate order i, o, f, u)
+    tr.epoch_reset()
+    want = sum(tr.window() for _ in range(windows)) / (S * (windows + S))
+    assert abs(float(m.group(1)) - want) <= 2e-3, (m.group(1), want)
+    # with the bias at 0 the same run reports a different loss: the flag reached the device
+    tr0 = oracle32.trainer(text, N, S, B, lr=lr, seed=5)
+    tr0.epoch_reset()
+    other = sum(tr0.window() for _ in range(windows)) / (S * (windows + S))
+    assert abs(other - want) > 2e-2
+    b = np.loadtxt(tmp_path / "fb_b.txt", ndmin=2)[:, 0]
+    assert np.all(np.abs(b[2 * N:3 * N] - 1.0) < 0.6) and np.all(np.abs(np.delete(b, np.s_[2 * N:3 * N])) < 0.6)
+
+
 def test_cli_rejects_bad_arguments():
     out = subprocess.run([LSTM, "/nonexistent.txt", "24", "5", "2", "0.1"], capture_output=True, text=True, timeout=60)
     assert out.returncode != 0

@@ -3,8 +3,10 @@
 The first Adagrad steps move every touched weight by +-lr*sign(d) (m = d^2, R/lstm.cc:261-272), so a rounding-level
 difference in a near-zero gradient flips a weight by 2*lr and the trajectories of any two implementations that round
 differently separate (hard part 2).  The free-running parity test therefore cannot use a fixed small
-tolerance; it is calibrated against CONTROLS: the oracle itself run (a) in float64 from the same float32 start and
-(b) in float32 with a few parameters, or all of them, moved by one ulp.  Every control is a correct implementation of
+tolerance; it is calibrated against CONTROLS: the oracle itself run (a) in float64 from the same float32 start,
+(b) in float32 with a few parameters, or all of them, moved by one ulp and (c) in float32 with every contraction summed
+in descending instead of ascending index order (the reference leaves that order to Eigen / BLAS).  Every control is a
+correct implementation of
 OV/lstm_eigen_opt/lstm.cc:186-318; their distance from the float32 oracle is the yardstick for the HIP path.
 """
 import numpy as np
@@ -43,6 +45,13 @@ def oracle_trajectories(oracle32, oracle64, text, N, S, B, windows, lr, seed=1, 
         p = t.params
         p[:] = np.nextafter(p, np.where(rs.rand(p.size) < 0.5, np.float32(np.inf), np.float32(-np.inf)).astype(np.float32))
         controls.append(np.array([t.window() for _ in range(windows)]))
+    # float32 arithmetic, every product of the window summed in descending index order (oracle/lstm_ref.c, ref_set_descending_sums)
+    oracle32.lib.ref_set_descending_sums(1)
+    try:
+        t = fresh(oracle32)
+        controls.append(np.array([t.window() for _ in range(windows)]))
+    finally:
+        oracle32.lib.ref_set_descending_sums(0)
     return base, controls
 
 
