@@ -1,0 +1,64 @@
+"""-m gpu: run-to-run determinism of the whole window loop over thousands of windows.
+
+Every kernel of the path sums in a fixed order, so two handles given the same seed and text must produce bit-identical
+losses and parameters.  What this soak is for: the recurrences hand data between workgroups through sentinel rings and
+between waves through relaxed LDS counters instead of barriers (csrc/persistent.hip); a race in such a hand-off with a
+rate of 1 in 10^4 windows passes every 1-12 window parity case and fails here.  tools/soak_determinism.py is the long
+form (>= 100 000 windows; its output is kept under profiles/)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(lstm_hip, text, N, S, B, windows, lr, chunk=1000):
+    L = lstm_hip.Lstm(N, S, B)
+    L.set_params(lstm_hip.init_params(lstm_hip.MT19937Normal(1), N))
+    L.set_text(text)
+    L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
+    losses = [L.train_windows(min(chunk, windows - w), lr) for w in range(0, windows, chunk)]
+    P = L.get_params()
+    L.close()
+    return np.concatenate(losses), P
+
+
+@pytest.mark.parametrize("N,S,B,windows", [
+    (512, 100, 64, 3000),   # BASELINE configs[2], the headline shape: two-half recurrences, fused sums, split-K dU slabs
+    (256, 50, 32, 3000),    # BASELINE configs[1]
+    (512, 20, 60, 3000),    # ragged batch: the last column group has a padded half
+    (1024, 12, 16, 1500),   # hidden size of configs[4]: one-recurrence forms, unfused products
+])
+def test_two_handles_same_seed_bit_identical(N, S, B, windows):
+    import lstm_hip
+    from bench import synthetic_text
+    text = synthetic_text(200_000, seed=0)
+    l0, p0 = _run(lstm_hip, text, N, S, B, windows, 0.005)
+    l1, p1 = _run(lstm_hip, text, N, S, B, windows, 0.005)
+    assert np.all(np.isfinite(l0))
+    assert np.array_equal(l0, l1), f"first differing window: {int(np.argmax(l0 != l1))}"
+    assert np.array_equal(p0, p1)
+
+
+def test_two_live_handles_interleaved_stay_identical():
+    """Both handles alive at once and advanced alternately (their kernels queue on one device): the same determinism,
+    plus isolation of the per-handle rings, counters and streams."""
+    import lstm_hip
+    from bench import synthetic_text
+    N, S, B = 512, 100, 64
+    text = synthetic_text(200_000, seed=0)
+    Ls = []
+    for _ in range(2):
+        L = lstm_hip.Lstm(N, S, B)
+        L.set_params(lstm_hip.init_params(lstm_hip.MT19937Normal(1), N))
+        L.set_text(text)
+        L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
+        Ls.append(L)
+    out = [[], []]
+    for _ in range(6):
+        for k, L in enumerate(Ls):
+            out[k].append(L.train_windows(250, 0.005))
+    P = [L.get_params() for L in Ls]
+    for L in Ls:
+        L.close()
+    assert np.array_equal(np.concatenate(out[0]), np.concatenate(out[1]))
+    assert np.array_equal(P[0], P[1])
