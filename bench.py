@@ -77,16 +77,23 @@ def kernel_flops(N, S, B, M=256, fused=True):
     }
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r2_pmc_traffic.json, else r1:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, gfx950 x2 read correction applied).  PMC
-    collection cannot run inside this process, so the figure is the recorded one; null if absent."""
-    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
-        try:
-            d = json.load(open(os.path.join(ROOT, "profiles", name)))
-            return d["kernels"][kernel]["hbm_bytes_per_launch"]
-        except Exception:
-            continue
+def pmc_traffic(kernel, N, S, B, dtype):
+    """HBM bytes per launch of `kernel` at THIS shape from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this bench, gfx950 x2 read correction applied; tools/pmc_traffic.py).  PMC collection cannot run
+    inside this process, so the figure is the recorded one; None for a shape (or kernel) that was not collected."""
+    key = f"{N}x{S}x{B}_{dtype}"
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))
+        return d["shapes"][key]["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    if key == "512x100x64_f32":  # earlier rounds collected the headline shape only (same recurrence kernels)
+        for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            try:
+                d = json.load(open(os.path.join(ROOT, "profiles", name)))
+                return d["kernels"][kernel]["hbm_bytes_per_launch"]
+            except Exception:
+                continue
     return None
 
 
@@ -268,7 +275,7 @@ def main():
             bf16_kernel = bool(args.flags & 128)  # every MFMA kernel of the bf16 path runs on the bf16 pipe
             peak = 2500.0 if bf16_kernel else PEAK_FP32_MFMA_TFLOPS
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None if bf16_kernel else pmc_traffic(dom),
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom, N, S, B, "bf16" if bf16_kernel else "f32"),
                         "avg_launch_us": round(avg_s * 1e6, 2), "flop_per_launch": fl[dom],
                         "window_frac": round((24.0 * N * N + 6.0 * 256 * N) * (value / world) / 1e12 / peak, 4)}
 
@@ -289,7 +296,10 @@ def main():
                                    f"{'bf16 MFMA path' if args.bf16 else 'fp32'}, {cfg['corpus']}-sized synthetic text "
                                    f"({len(text)} bytes), stride-1 windows from a full window, Adagrad lr=%g" % lr,
                        "parallelism": f"dp{world}" if world > 1 else "single",
-                       "engine": "step-kernels" if (args.flags & lstm_hip.STEP_KERNELS) else "default"},
+                       "engine": "step-kernels" if (args.flags & lstm_hip.STEP_KERNELS) else "default",
+                       # every product of the window is one of the library's own kernels (csrc/gemm.hip for the time-batched
+                       # ones); it links and loads no BLAS
+                       "gemm": "native"},
             "device_ms_per_step": round(dev_ms / args.steps, 4),
             "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
             "sustained": sustained,

@@ -164,13 +164,21 @@ struct lstm_hip_ctx {
 
 namespace {
 
+// Every launch is checked: a kernel that could not be launched (resources, an attribute that was refused) must not leave the
+// window to complete "successfully" on stale buffers.
+int launch_status(int id) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LSTM_HIP_EHIP, "launch of %s failed: %s", kKernelNames[id], hipGetErrorString(e));
+    return 0;
+}
 template <class F> int timed(lstm_hip_ctx *h, int id, F &&launch) {
     if (!h->profiling) {
         launch();
-        return 0;
+        return launch_status(id);
     }
     HIP_TRY(hipEventRecord(h->ev0, h->st));
     launch();
+    if (int rc = launch_status(id)) return rc;
     HIP_TRY(hipEventRecord(h->ev1, h->st));
     HIP_TRY(hipEventSynchronize(h->ev1));
     float ms = 0.f;
@@ -950,7 +958,20 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
     h->in_loop = true;
     struct LoopGuard { // leaves the loop state clean on every return path
         lstm_hip_ctx *h;
-        ~LoopGuard() { h->in_loop = false; }
+        bool completed = false;
+        ~LoopGuard() {
+            h->in_loop = false;
+            if (completed) return;
+            // error exit somewhere inside a window: nothing of that window may leak into a later standalone call
+            h->fold_pending = false;
+            h->early_reduced = false;
+            h->dU_reduced = 0;
+            h->n_slabs_dU = 0;
+            h->dby_done = false;
+            h->fwd_done = false;
+            if (h->st2) (void)hipStreamSynchronize(h->st2); // side-stream work of the broken window (folds, early all-reduce)
+            if (h->st) (void)hipStreamSynchronize(h->st);
+        }
     } guard{h};
     for (int64_t i = 0; i < count; i++) {
         RUN(K_SLIDE, slide_window(h->text, h->text_len, h->pos, h->Xr, h->Tr, h->head, h->xi, h->ti, h->H, h->C,
@@ -973,6 +994,7 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
         HIP_TRY(hipMemcpyAsync(h->h_losses, h->d_losses, sizeof(double) * count, hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
     if (losses && count > 0) std::memcpy(losses, h->h_losses, sizeof(double) * count);
+    guard.completed = true;
     return check_abort(h);
 }
 
