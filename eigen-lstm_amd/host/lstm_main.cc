@@ -26,6 +26,8 @@
 #include "matrix_io.h"
 #include "rng.h"
 
+#include <errno.h>
+#include <poll.h>
 #include <signal.h>
 #include <sys/time.h>
 #include <sys/wait.h>
@@ -467,24 +469,70 @@ int main(int argc, char **argv) {
     if (read(up_r[0], id, sizeof(id)) != (ssize_t)sizeof(id)) die("rank 0 did not produce a unique id");
     for (int r = 0; r < o.gpus; r++)
         if (write(down_w[r], id, sizeof(id)) != (ssize_t)sizeof(id)) die("relay");
+    // The relay never blocks on ONE rank's pipe: a rank that fails (a non-finite window, a hand-off time-out, a HIP error)
+    // leaves the others blocked inside the next all-reduce, so its death must be noticed while its peers are silent.
+    // poll() over all pipes with a short time-out, children reaped without blocking in between.
     bool relay_failed = false;
+    std::vector<bool> done(o.gpus, false);
+    int live = o.gpus, rc = 0;
+    auto reap_nonblocking = [&]() {
+        for (;;) {
+            int st = 0;
+            const pid_t p = waitpid(-1, &st, WNOHANG);
+            if (p <= 0) break;
+            for (int r = 0; r < o.gpus; r++)
+                if (kids[r] == p && !done[r]) {
+                    done[r] = true;
+                    live--;
+                    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+                        rc = 1;
+                        relay_failed = true;
+                    }
+                }
+        }
+    };
     for (long e = 0; e < o.epochs && !relay_failed; e++) {
         double sum = 0.0;
-        for (int r = 0; r < o.gpus; r++) {
-            double v = 0.0;
-            if (read(up_r[r], &v, sizeof(v)) != (ssize_t)sizeof(v)) relay_failed = true; // EOF: that rank is gone
-            sum += v;
+        std::vector<double> part(o.gpus, 0.0);
+        std::vector<bool> got(o.gpus, false);
+        int missing = o.gpus;
+        while (missing > 0 && !relay_failed) {
+            std::vector<pollfd> fds;
+            std::vector<int> who;
+            for (int r = 0; r < o.gpus; r++)
+                if (!got[r]) {
+                    fds.push_back(pollfd{up_r[r], POLLIN, 0});
+                    who.push_back(r);
+                }
+            const int n = poll(fds.data(), (nfds_t)fds.size(), 200);
+            if (n < 0 && errno != EINTR) relay_failed = true;
+            for (size_t k = 0; k < fds.size() && n > 0; k++) {
+                if (!(fds[k].revents & (POLLIN | POLLHUP | POLLERR))) continue;
+                double v = 0.0;
+                if (read(fds[k].fd, &v, sizeof(v)) != (ssize_t)sizeof(v)) { // EOF: that rank is gone
+                    relay_failed = true;
+                    break;
+                }
+                part[who[k]] = v;
+                got[who[k]] = true;
+                missing--;
+            }
+            reap_nonblocking(); // a child that ended (badly, or before delivering) while its peers are blocked
+            if (live < o.gpus && missing > 0) {
+                for (int r = 0; r < o.gpus; r++)
+                    if (done[r] && !got[r]) relay_failed = true; // it will never deliver
+            }
         }
         if (relay_failed) break;
+        for (int r = 0; r < o.gpus; r++) sum += part[r]; // rank order: the same sum on every run
         for (int r = 0; r < o.gpus; r++)
             if (write(down_w[r], &sum, sizeof(sum)) != (ssize_t)sizeof(sum)) relay_failed = true;
     }
     // Reap.  A rank that fails (a non-finite window, a hand-off time-out, a HIP error) leaves the others blocked inside the
     // next all-reduce: as soon as the relay breaks or any child ends badly, the remaining children are terminated instead
     // of waited for.
-    int rc = 0, live = o.gpus;
     bool failed = relay_failed;
-    std::vector<bool> done(o.gpus, false);
+    if (failed) rc = 1;
     while (live > 0) {
         if (failed)
             for (int r = 0; r < o.gpus; r++)
