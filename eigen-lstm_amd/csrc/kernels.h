@@ -75,11 +75,10 @@ void bwd_halves(const float4 *Ubwd5, float *DG, const float *Why, const float *d
 // gpart != null (8-column groups only): fused mode.  The recurrence then also produces DHy on the fly from
 // Why and dY (DHy is not read), and leaves per-column-group partial blocks [dW | - | db | dWhy]
 // (bwd_partial_floats(N) floats each) to be folded in group order; H and xi are read as well.
-// DGx != null (fp32 4x4x1 form only): data-as-flag hand-off through the ring.
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,
                     const int32_t *xi, float *gpart, const float *Why, const float *dY, unsigned *cnt, unsigned *abortp,
                     unsigned epoch, int N, int S, int B, int cols, hipStream_t st, unsigned long long *stamps = nullptr,
-                    unsigned short *DGb = nullptr, float *DGx = nullptr, int ring_base = 0);
+                    unsigned short *DGb = nullptr);
 size_t bwd_ring_floats(int N, int B);
 int bwd_ring_advance(int ring_base, int S);
 // bf16 recurrence (N % 128 == 0): bf16 fragment images of U (N*N*8 bytes each), h and dg also kept as bf16

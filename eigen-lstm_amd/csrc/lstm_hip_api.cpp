@@ -361,9 +361,7 @@ int do_backward(lstm_hip_ctx *h) {
         } else {
             RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd4 ? h->Ubwd4 : h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi,
                                               fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp, h->bwd_epoch, N, S,
-                                              B, h->bwd_cols, h->st, h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr, nullptr,
-                                              h->DGx, h->ring_base_b));
-            if (h->DGx) h->ring_base_b = bwd_ring_advance(h->ring_base_b, S);
+                                              B, h->bwd_cols, h->st, h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr, nullptr));
         }
     } else {
         HIP_TRY(hipMemsetAsync(h->dcnext, 0, sizeof(float) * N * B, h->st)); // R/lstm.cc:216-217
@@ -657,14 +655,12 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     }
     if (h->persistent && bwd_uses_m4((int)N, h->bwd_cols, h->bf16)) {
         ALLOC(h->Ubwd4, N * N);
-        // hand-off of the backward recurrence: sharded counters (default) or the data-as-flag ring ("flag"); read per handle
-        const char *e = getenv("LSTM_HIP_BWD_HANDOFF");
         const char *bh = getenv("LSTM_HIP_BWD_HALVES");
         h->side_stream = !(getenv("LSTM_HIP_NO_SIDE_STREAM") && atoi(getenv("LSTM_HIP_NO_SIDE_STREAM")));
         // two-half form wherever it exists; "0" selects the one-recurrence form (A/B), other values are tuning bits (<< 1)
         const int bhv = bh ? atoi(bh) : 7; // 7: hint poll, no early request for half A (measured 347 us; 5 = no hint: 368)
         h->bwd_halves = bhv == 0 ? 0 : (bhv | 1) * (int)bwd_halves_supported((int)N, (int)B, prop.multiProcessorCount, want_fused);
-        if ((e && e[0] == 'f') || h->bwd_halves) {
+        if (h->bwd_halves) { // the two-half form hands dg over through a sentinel ring
             ALLOC(h->DGx, bwd_ring_floats((int)N, (int)B));
             HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * bwd_ring_floats((int)N, (int)B)));
         }

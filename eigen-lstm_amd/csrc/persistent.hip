@@ -17,7 +17,7 @@
 //   backward  k_bwd_halves        N = 512 / 256, 8-column groups: two alternating 4-column recurrences, side waves for the
 //                                 output-layer term and the dW / db / dWhy sums                           (the headline shape)
 //             k_bwd_persistent    everything else: 16x16x4 tiles or 4x4x1 blocks, 4 / 8 / 16-column groups, fp32 or bf16,
-//                                 sharded counters (or the ring, LSTM_HIP_BWD_HANDOFF=flag), optional fused sums
+//                                 sharded counters, optional fused sums
 //
 // Hand-off, counter form (first / second forward forms, k_bwd_persistent; cdna_hip_programming.md Guideline 16): the
 // producing wave stores its slice of h_t with sc1 (write-through) 16-byte stores, drains them (s_waitcnt vmcnt(0)), then ONE
@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
 //              so a lane's 16-byte load m (lane = 16Y + 4z' + i: 16 consecutive bytes of k, 256 per column) feeds
 //              sixteen instructions; weights Ubwd5 (ubwd5_index), 64 registers; 64 instructions per half and step.
 //   wave 8 / 9 elementwise (R/lstm.cc:228-247,256) of half A / B: lane = column*16 + unit, folds the 8 x 4 (wave, Y)
-//              partial sums, publishes dg_t to the ring DGx (data-as-flag, as in k_bwd_persistent<.., DF>) and stores
+//              partial sums, publishes dg_t to the ring DGx (data-as-flag, as in the forward kernels) and stores
 //              the plain DG the dU product reads after the launch.  In the time it would otherwise wait for the next
 //              product it does the output-layer work of the NEXT step on the vector ALU (the matrix pipe belongs to the
 //              chain; the same work as 4x4x1 instructions in this wave measured +25 us a window):
@@ -1851,12 +1851,7 @@ template <int N_, bool FUSE, bool STAMP = false> __global__ __launch_bounds__(BW
 // gradient block) in gpart[g]; gemm_fold adds the groups in order afterwards.
 // (Accumulating dU the same way -- 4 x N/16 MFMA accumulator tiles per workgroup -- was built and
 // measured: it needs ~100 more VGPRs, spills, and cost more than the separate GEMM it replaced.)
-// DF (fp32 M4 form only): the data-as-flag hand-off of k_fwd_persistent4 -- dg_t goes into a ring DGx[HX_RING][B][4N] of
-// sentinel-initialised step slots (slot(t) = (t + ring_base) & 3; the backward recurrence walks t downwards, so step t
-// reads slot(t+1), publishes slot(t) and then resets its own words of slot(t-2)); every wave polls the loads of its own
-// K-slice; no counters, no drain, no barrier ahead of the loads (`red` is double-buffered by step parity instead).
-// The plain DG, which the dU product reads after the launch, is stored off the chain.
-template <int NR4W, int COLS, bool FUSE, bool STAMP = false, bool BF16 = false, bool M4 = false, bool DF = false>
+template <int NR4W, int COLS, bool FUSE, bool STAMP = false, bool BF16 = false, bool M4 = false>
 __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restrict__ Ubwd, float *DG,
                                                            const float *__restrict__ DHy, const float *__restrict__ G,
                                                            const float *__restrict__ C, const float *__restrict__ H,
@@ -1864,9 +1859,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                                                            const float *__restrict__ Why, const float *__restrict__ dY,
                                                            unsigned *cnt, unsigned *abortp, unsigned epoch, int S, int B,
                                                            int spread, unsigned long long *stamps = nullptr,
-                                                           unsigned short *DGb = nullptr, float *DGx = nullptr,
-                                                           int ring_base = 0) {
-    static_assert(!DF || (M4 && !BF16), "the data-as-flag hand-off exists for the fp32 4x4x1 form");
+                                                           unsigned short *DGb = nullptr) {
     static_assert(!STAMP || M4, "stamped builds exist for the fp32 4x4x1 form");
     constexpr int N = 32 * NR4W, G4 = 4 * N, nr4 = N / 4;
     // BF16: Ubwd holds the bf16 image (N/64 16-byte fragments per wave), dg_{t+1} is read from the bf16 copy DGb
@@ -1875,7 +1868,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     constexpr int ETH = 16 * COLS;        // threads with an elementwise / store role
     constexpr int EW = ETH / 64;          // ... i.e. waves 0..EW-1
     extern __shared__ __attribute__((aligned(16))) float dWt[]; // FUSE: [257][64] per-input-byte sums of this WG's rows
-    __shared__ float red[(DF ? 2 : 1) * 8 * 4 * 64];
+    __shared__ float red[8 * 4 * 64];
     __shared__ __attribute__((aligned(16))) float stage[2][16 * 4 * 16]; // dg of this WG, double-buffered by step parity
     __shared__ int s_abort;
     // FUSE: output-layer followers (waves 4..7): DHy_t = Why^T * dy_t for this workgroup's units, one step
@@ -1908,7 +1901,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                : M4 ? Ubwd[(((size_t)kb * 8 + w) * NR4W + i) * 64 + l] // the 4x4x1 image: see k_pack_U
                     : Ubwd[((size_t)kb * nr4 + w * NR4W + i) * 64 + l];
     const __amdgpu_buffer_rsrc_t rDG = BF16 ? make_rsrc(DGb, (size_t)S * G4 * B * sizeof(unsigned short))
-                                       : DF ? make_rsrc(DGx, (size_t)HX_RING * G4 * B * sizeof(float))
                                             : make_rsrc(DG, (size_t)S * G4 * B * sizeof(float));
     float dcn = 0.0f; // dcnext, R/lstm.cc:217
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1929,7 +1921,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     if (XCD_LOCAL && tid == 0) {
         __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT); // getreg(id 20 = XCC_ID, offset 0, size 4)
-        if (DF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // ahead of the barrier below: visible before any dg
     }
     unsigned ol_target = 0;
     bool local_pub = false;
@@ -2069,7 +2060,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
             if (!FUSE) dhy = DHy[((size_t)t * B + ecolc) * N + j];
         }
         if (FUSE && w >= 4 && t >= 2) output_layer_fetch(t - 1);
-        if (!DF && has_next && w == 0) {
+        if (has_next && w == 0) {
             const unsigned *cpn = cnt + (size_t)((t + 1) * NG + g) * CNT_SLOTS * CNT_STRIDE;
             if (!wait_arrivals<BWD_SH>(cpn, NBK, epoch * EW, abortp, l) && l == 0) s_abort = 1;
             if (XCD_LOCAL && t == S - 2) { // every workgroup of the group has published its XCC id by now
@@ -2086,13 +2077,11 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                 if ((XCD_FORCE_LOCAL || __all(same)) && l == 0) s_local = 1;
             }
         }
-        if (!DF) {
-            __syncthreads();
-            if (s_abort) return;
-            if (XCD_LOCAL && t == S - 2) local_pub = s_local != 0; // decided by wave 0 just above; kept in a register
-        }
+        __syncthreads();
+        if (s_abort) return;
+        if (XCD_LOCAL && t == S - 2) local_pub = s_local != 0; // decided by wave 0 just above; kept in a register
         BSTAMP(0, 1) BSTAMP(3, 9)
-        float *redp = red + (DF ? (t & 1) * (8 * 4 * 64) : 0);
+        float *redp = red;
 
         float dhn = 0.0f;
         if (M4 && has_next) {
@@ -2116,64 +2105,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
     c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.y, c1, 2, 1, blgp);                 \
     c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.z, c2, 2, 2, blgp);                 \
     c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.w, c3, 2, 3, blgp);
-            if (DF) {
-                // Data-as-flag with a HINT.  A wave's K-slice is 8 loads per lane (64 KB per workgroup and step: re-issuing
-                // all of them as a poll floods the XCD's L2 -- measured 523 us against 409 with counters).  So: (1) poll ONE
-                // load instruction that touches one 16-byte piece of each of the N/16 producer waves this K-slice comes
-                // from (the piece each stores from its last lane); (2) once those are in, run the usual pipelined loads +
-                // MFMAs, checking every loaded word against the sentinel on the side; (3) in the rare case that some word
-                // had not landed yet (a store instruction's lanes do not land together), drop the sums and repeat (2).
-                // Correctness rests on (2)'s check of every consumed word alone; (1) only decides when to start.
-                const size_t slot_base = (size_t)((t + 1 + ring_base) & (HX_RING - 1)) * B * G4;
-                const int offx = (int)((slot_base + (size_t)col4c * G4 + Kw * w + 4 * (2 * lz + ly)) * sizeof(float));
-                const int gate_k = (Kw * w) / N, unit0 = (Kw * w) % N; // this wave's gate rows: gate_k, units unit0 .. unit0 + Kw
-                const bool hint_lane = l < Kw / 8;                      // Kw/16 producer workgroups x 2 storing waves
-                int hcol = COLS * g + 4 * (l & 1) + 3;
-                hcol = hcol < B ? hcol : B - 1;
-                const int hoff = (int)((slot_base + (size_t)hcol * G4 + gate_k * N + unit0 + 16 * (l >> 1) + 12) * sizeof(float));
-                bool ok = false;
-                int spins = 0;
-                for (; spins <= SPIN_LIMIT; spins++) {
-                    float4 hv = {0.f, 0.f, 0.f, 0.f};
-                    if (hint_lane) hv = ld_sc1(rDG, hoff);
-                    if (__all(hx_ready(hv))) break;
-                    if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        spins = SPIN_LIMIT + 1;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                BSTAMP(0, 2) BSTAMP(3, 10) BSTAMP_VAL(0, 6, spins)
-                const int spins_hint = spins;
-                for (; spins <= SPIN_LIMIT; spins++) {
-                    bool good = true;
-                    c0 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    c1 = c0, c2 = c0, c3 = c0;
-#pragma unroll
-                    for (int i = 0; i < PF; i++) b[i] = ld_sc1(rDG, offx + 128 * i);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < NL; i++) {
-                        if (i + PF < NL) b[i + PF] = ld_sc1(rDG, offx + 128 * (i + PF));
-                        good = good && hx_ready(b[i]);
-                        M4_STEP(b[i].x, a[2 * i], 1)
-                        M4_STEP(b[i].y, a[2 * i], 2)
-                        M4_STEP(b[i].z, a[2 * i + 1], 1)
-                        M4_STEP(b[i].w, a[2 * i + 1], 2)
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (__all(good)) {
-                        ok = true;
-                        break;
-                    }
-                    if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                }
-                BSTAMP_VAL(0, 7, spins - spins_hint)
-                if (!ok && l == 0) {
-                    __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    s_abort = 1;
-                }
-            } else {
 #pragma unroll
             for (int i = 0; i < PF; i++) b[i] = ld_sc1(rDG, off + 128 * i);
             __builtin_amdgcn_sched_barrier(0);
@@ -2186,7 +2117,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                 M4_STEP(b[i].w, a[2 * i + 1], 2)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            }
 #undef M4_STEP
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -2196,7 +2126,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
             }
             BSTAMP(0, 3) BSTAMP(3, 11) BSTAMP(5, 14)
             __syncthreads();
-            if (DF && s_abort) return;
             BSTAMP(0, 4) BSTAMP(3, 12) BSTAMP(5, 15)
         } else if (has_next) {
             // Software pipeline with PF fragment loads in flight ahead of the MFMAs.  Left to itself the
@@ -2239,21 +2168,8 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
 #pragma unroll
             for (int r = 0; r < 4; r++) red[(w * 4 + r) * 64 + l] = acc0[r] + acc1[r];
             __syncthreads();
-        } else if (DF) {
-            __syncthreads(); // t = S-1: the one workgroup barrier of a step (LDS hand-offs to the followers and the dW wave)
         }
         if (w < EW) {
-            if (DF && XCD_LOCAL && t == S - 2) { // every workgroup of the group has published dg_{S-1}, its XCC id before it
-                unsigned mine = 0;
-                bool same = true;
-                if (l < NBK) {
-                    mine = __hip_atomic_load(xcc_tab + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    same = (mine >> 4) == epoch;
-                }
-                const unsigned first = __builtin_amdgcn_readfirstlane(mine);
-                if (l < NBK) same = same && mine == first;
-                local_pub = (XCD_FORCE_LOCAL || __all(same)) && NBK <= 64;
-            }
             if (FUSE) dhy = dhyb[cur][cc * 16 + jj]; // written by the followers one step ago (before barrier A)
             if (has_next) {
                 // D[row = 4*(lane>>4) + reg][col = lane&15]  ->  unit jj lives in lane (jj>>2)*16 + cc, reg jj&3
@@ -2302,7 +2218,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                 }
             }
             BSTAMP(0, 5)
-            if (DF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's older stores (the last reset) are complete
             const float4 v = {t0, t1, t2, t3};
             float4 v2 = v;
             if (BF16) { // the next quad's four units of the same gate: lane + 4 within the row of 16 (row_shl:4)
@@ -2319,22 +2234,6 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                         if (XCD_LOCAL && local_pub) *reinterpret_cast<u32x4 *>(DGb + eoff) = pack_bf16x8(v, v2);
                         else __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v, v2), rDG, (int)(eoff * sizeof(unsigned short)), 0, 16);
                     }
-                } else if (DF) {
-                    const float4 vp = {hx_canon(v.x), hx_canon(v.y), hx_canon(v.z), hx_canon(v.w)};
-                    const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
-                                         __uint_as_float(HX_SENT)};
-                    const size_t within = (size_t)ecol * G4 + ta * N + 16 * kb + 4 * tq;
-                    const size_t e_pub = (size_t)((t + ring_base) & (HX_RING - 1)) * B * G4 + within;
-                    const size_t e_rst = (size_t)((t - 2 + ring_base) & (HX_RING - 1)) * B * G4 + within;
-                    // (the s_waitcnt vmcnt(0) ahead of this block covers the reset issued a step ago)
-                    if (XCD_LOCAL && local_pub) {
-                        *reinterpret_cast<float4 *>(DGx + e_pub) = vp;
-                        *reinterpret_cast<float4 *>(DGx + e_rst) = sent;
-                    } else {
-                        st_sc1(vp, rDG, (int)(e_pub * sizeof(float)));
-                        st_sc1(sent, rDG, (int)(e_rst * sizeof(float)));
-                    }
-                    *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
                 } else {
                     if (XCD_LOCAL && local_pub)
                         *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
@@ -2342,7 +2241,7 @@ __global__ __launch_bounds__(512, 2) void k_bwd_persistent(const float4 *__restr
                         st_sc1(v, rDG, (int)((((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) * sizeof(float)));
                 }
             }
-            if (!DF && t > 1) {
+            if (t > 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains, then signals for itself:
                                                                  // EW arrivals per workgroup and step
                 if (l == 0)
@@ -2477,8 +2376,8 @@ bool persistent_supported(int N, int B, int n_cus, bool fused) {
     switch (N / 32) {
 #define X(k)                                                                                                           \
     case k:                                                                                                            \
-        if (cols == 8 && fuse) bb = blocks_per_cu(k_bwd_persistent<k, 8, true, false, false, true, true>, 512, lds);   \
-        else if (cols == 8) bb = blocks_per_cu(k_bwd_persistent<k, 8, false, false, false, true, true>, 512, 0);       \
+        if (cols == 8 && fuse) bb = blocks_per_cu(k_bwd_persistent<k, 8, true, false, false, true>, 512, lds);         \
+        else if (cols == 8) bb = blocks_per_cu(k_bwd_persistent<k, 8, false, false, false, true>, 512, 0);             \
         else bb = blocks_per_cu(k_bwd_persistent<k, 16, false>, 512, 0);                                               \
         break;
         BWD_CASES(X)
@@ -2706,7 +2605,7 @@ void bwd_halves(const float4 *Ubwd5, float *DG, const float *Why, const float *d
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,
                     const int32_t *xi, float *gpart, const float *Why, const float *dY, unsigned *cnt, unsigned *abortp,
                     unsigned epoch, int N, int S, int B, int cols, hipStream_t st, unsigned long long *stamps,
-                    unsigned short *DGb, float *DGx, int ring_base) {
+                    unsigned short *DGb) {
     const dim3 grid(N / 16, (B + cols - 1) / cols), block(512);
     const bool fuse = gpart != nullptr;
     const size_t lds = fuse ? DW_TABLE_BYTES : 0;
@@ -2717,7 +2616,7 @@ void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float
         if (fuse) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_persistent<__VA_ARGS__>),           \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_TABLE_BYTES);          \
         hipLaunchKernelGGL((k_bwd_persistent<__VA_ARGS__>), grid, block, lds, st, Ubwd, DG, DHy, G, C, H, xi, gpart, Why, dY, cnt, \
-                           abortp, epoch, S, B, spread, stamps, DGb, DGx, ring_base);                                   \
+                           abortp, epoch, S, B, spread, stamps, DGb);                                                  \
     } while (0)
     if (DGb != nullptr) { // bf16 recurrence: 8- or 16-column groups, 16x16x32 tiles, counter hand-off
         switch (N / 32) {
@@ -2735,26 +2634,16 @@ void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float
     }
     if (bwd_uses_m4(N, cols, false)) { // Ubwd is the 4x4x1 image here (the caller packs it when bwd_uses_m4 says so)
         if (stamps != nullptr && N == 512) { // diagnostic build of the headline shape
-            if (DGx != nullptr) {
-                if (fuse) BWD_GO(16, 8, true, true, false, true, true);
-                else BWD_GO(16, 8, false, true, false, true, true);
-            } else {
-                if (fuse) BWD_GO(16, 8, true, true, false, true, false);
-                else BWD_GO(16, 8, false, true, false, true, false);
-            }
+            if (fuse) BWD_GO(16, 8, true, true, false, true);
+            else BWD_GO(16, 8, false, true, false, true);
             return;
         }
         stamps = nullptr;
         switch (N / 32) {
 #define X(k)                                                                   \
     case k:                                                                    \
-        if (DGx != nullptr) {                                                  \
-            if (fuse) BWD_GO(k, 8, true, false, false, true, true);            \
-            else BWD_GO(k, 8, false, false, false, true, true);                \
-        } else {                                                               \
-            if (fuse) BWD_GO(k, 8, true, false, false, true, false);           \
-            else BWD_GO(k, 8, false, false, false, true, false);               \
-        }                                                                      \
+        if (fuse) BWD_GO(k, 8, true, false, false, true);                      \
+        else BWD_GO(k, 8, false, false, false, true);                          \
         break;
             X(2) X(4) X(8) X(16) X(32)
 #undef X

@@ -160,34 +160,6 @@ def test_fast_math_flag_stays_close(oracle32):
     assert abs(got["loss"] - fw["loss_bits"]) <= 1e-4 * (S - 1)
 
 
-def test_backward_data_as_flag_handoff_matches_oracle(oracle32, monkeypatch):
-    """LSTM_HIP_BWD_HANDOFF=flag (read per handle at create): the backward recurrence hands dg over through the sentinel
-    ring (hint poll + checked, pipelined loads) instead of the sharded counters.  Same window, same tolerances, across
-    several windows so that the ring wraps and its slots are reused between launches (S-1 not a multiple of 4)."""
-    import lstm_hip
-    from oracle_lib import Oracle
-    N, S, B = 256, 12, 64
-    monkeypatch.setenv("LSTM_HIP_BWD_HANDOFF", "flag")
-    monkeypatch.setenv("LSTM_HIP_BWD_HALVES", "0")  # the one-recurrence form (the two-half form always uses the ring)
-    L = lstm_hip.Lstm(N, S, B)
-    monkeypatch.delenv("LSTM_HIP_BWD_HANDOFF")
-    monkeypatch.delenv("LSTM_HIP_BWD_HALVES")
-    orc = Oracle("f32_omp")
-    for rep in range(5):
-        P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=300 + rep, empty=((1, rep),))
-        fw = orc.forward(N, 256, S, B, P, xi, ti, h0, c0)
-        dref = orc.backward(N, 256, S, B, P, xi, ti, fw)
-        L.set_params(P)
-        L.set_state(0, h0, c0)
-        L.set_window(xi, ti)
-        L.forward()
-        assert abs(L.loss() - fw["loss_bits"]) <= LOSS_TOL * (S - 1)
-        L.backward()
-        rep_ = gu.grads_report(L.get_grads(), dref, N)
-        assert max(rep_.values()) <= GRAD_TOL, (rep, rep_)
-    L.close()
-
-
 @pytest.mark.parametrize("fused,B", [(True, 60), (False, 60), (True, 59)])
 @pytest.mark.parametrize("N", [512, 256])
 def test_backward_two_half_form_matches_oracle(oracle32, monkeypatch, fused, B, N):

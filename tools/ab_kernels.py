@@ -4,7 +4,7 @@ library's own HIP-event profiling; prints median / min microseconds per kernel.
 
   python tools/ab_kernels.py [N S B] [--rounds R] [--windows W] name=ENV1:val,ENV2:val ...
 
-e.g.  python tools/ab_kernels.py counters=LSTM_HIP_BWD_HANDOFF:counter flag=LSTM_HIP_BWD_HANDOFF:flag poll0=LSTM_HIP_FWD_POLL:0
+e.g.  python tools/ab_kernels.py halves=LSTM_HIP_BWD_HALVES:7 one=LSTM_HIP_BWD_HALVES:0 poll0=LSTM_HIP_FWD_POLL:0
 """
 import os
 import statistics

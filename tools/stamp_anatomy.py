@@ -1,7 +1,7 @@
 """Diagnostic: where does a step of each recurrence spend its cycles?  (LSTM_HIP_DEBUG_STAMPS builds, headline shape)
 
   python tools/stamp_anatomy.py            # forward (data-as-flag) + backward with the default hand-off
-  LSTM_HIP_BWD_HANDOFF=flag python tools/stamp_anatomy.py
+  LSTM_HIP_BWD_HALVES=0 LSTM_HIP_FWD_HALVES=0 python tools/stamp_anatomy.py   (the one-recurrence forms)
 
 Stamps are s_memtime values (shader cycles) of lane 0 of three waves of two workgroups; slot meanings are in
 persistent.hip (FSTAMP / BSTAMP).  A stamped build forbids overlaps the real kernel has: read the SHARES, not the length.
@@ -104,7 +104,7 @@ if os.environ.get("LSTM_HIP_BWD_HALVES", "7") != "0":   # two-half backward form
     print(np.array2string((s[tt, 8] - s[S - 1, 3]).astype(np.int64), max_line_width=150))
     sys.exit(0)
 
-df = os.environ.get("LSTM_HIP_BWD_HANDOFF", "c")[0] == "f"
+df = False  # (the data-as-flag variant of the one-recurrence backward form was removed in round 3)
 for wg in (2, 3):
     s = st[wg]
     t = np.arange(S - 4, 3, -1)      # steps run S-1 .. 1; step t-1 follows step t
