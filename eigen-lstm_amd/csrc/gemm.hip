@@ -345,6 +345,12 @@ int gemm_regs(bool akf, bool bkf, int M, int Nn, int K, const float *A, int lda,
     return splits;
 }
 
+// timing probe only (LSTM_HIP_PROBE_OVERLAP): the Y-shaped product on 64 x 64 tiles -- 64 KB of LDS and ~100 registers, small
+// enough to be co-resident with a workgroup of the forward recurrence on the same compute unit
+void gemm_probe_small_kfast(int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, hipStream_t st) {
+    launch_regs<false, true, 2, 2, 4, 2>(M, Nn, K, A, lda, B, ldb, C, ldc, 1, (K + 7) / 8 * 8, 0, st);
+}
+
 // the (TA, TB) form the rest of the library speaks: op(A) is k fast when TA, op(B) is k fast when !TB
 void gemm(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int splits,
           float *slabs, hipStream_t st) {

@@ -72,6 +72,15 @@ bool bwd_halves_supported(int N, int B, int n_cus, bool fused);
 void bwd_halves(const float4 *Ubwd5, float *DG, const float *Why, const float *dY, const float *G, const float *C, const float *H,
                 const int32_t *xi, float *gpart, float *DGx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N,
                 int S, int B, int cfg, hipStream_t st, unsigned long long *stamps = nullptr);
+// scatter form of the backward recurrence (N = 512 / 256, 8-column groups; the default where it exists): every workgroup
+// multiplies its OWN dg_t into partial sums for all N outputs and scatters them to the owners of the outputs, instead of
+// gathering all of dg_{t+1}.  Ubwd6 image (pack_U / adagrad with bit 2 of half_forms), partial-sum ring Qx (bwd_ring_floats
+// floats, sentinel-filled like the other rings; ring_base moves by bwds_ring_advance).  Arguments otherwise as bwd_halves.
+bool bwd_scatter_supported(int N, int B, int n_cus, bool fused);
+int bwds_ring_advance(int ring_base, int S);
+void bwd_scatter(const float4 *Ubwd6, float *DG, const float *Why, const float *dY, const float *G, const float *C, const float *H,
+                 const int32_t *xi, float *gpart, float *Qx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N,
+                 int S, int B, int cfg, hipStream_t st, unsigned long long *stamps = nullptr);
 // gpart != null (8-column groups only): fused mode.  The recurrence then also produces DHy on the fly from
 // Why and dY (DHy is not read), and leaves per-column-group partial blocks [dW | - | db | dWhy]
 // (bwd_partial_floats(N) floats each) to be folded in group order; H and xi are read as well.
@@ -105,6 +114,7 @@ void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc,
 // the split-K product without its fold (slabs densely packed, M*Nn floats each); returns the number of slabs written
 int gemm_slabs(bool TA, bool TB, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *slabs, int splits,
                hipStream_t st);
+void gemm_probe_small_kfast(int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, hipStream_t st);
 // the same by operand layout ("k fast": the contraction index is the contiguous one); gemm / gemm_slabs map onto these
 int gemm_regs_splits(bool a_kfast, bool b_kfast, int M, int Nn, int K, int n_cus);
 int gemm_regs(bool a_kfast, bool b_kfast, int M, int Nn, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,

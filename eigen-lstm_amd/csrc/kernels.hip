@@ -81,12 +81,21 @@ __device__ __forceinline__ size_t ubwd5_index(int gk, int hr, int N) { // float 
     const int Y = rem >> 4, zp = (rem >> 2) & 3, r = rem & 3, l = 16 * Y + (hr & 15);
     return ((((((size_t)(hr >> 4) * 8 + w) * (N / 128) + m) * 4 + r) * 64 + l) * 4) + zp;
 }
-// half_forms: bit 0 = the forward image is Ufwd5, bit 1 = the backward image is Ubwd5
+//   Ubwd6[kb][w][ab][l].r (the scatter form of the backward recurrence, k_bwd_scatter; stored through the Ubwd4 pointer when
+//        bit 2 of `half_forms` is set): workgroup kb keeps the 64 gate rows of ITS units, k = gate*16 + (unit - 16*kb) = 4*ab + r,
+//        for all N outputs: wave w owns outputs [64w, 64w+64), lane l = 4*block + j is output 64w + l;
+//        = U[gate*N + 16*kb + unit][64*w + l]
+__device__ __forceinline__ size_t ubwd6_index(int gk, int hr, int N) { // float index of U[gk][hr] in Ubwd6
+    const int gate = gk / N, unit = gk % N, kb = unit >> 4, kk = gate * 16 + (unit & 15);
+    const int w = hr >> 6, l = hr & 63;
+    return ((((size_t)kb * (N / 64) + w) * 16 + (kk >> 2)) * 64 + l) * 4 + (kk & 3);
+}
+// half_forms: bit 0 = the forward image is Ufwd5, bit 1 = the backward image is Ubwd5, bit 2 = the backward image is Ubwd6
 __device__ __forceinline__ size_t ufwd45_index(int row, int k, int N, int half_forms) {
     return (half_forms & 1) ? ufwd5_index(row, k, N) : ufwd4_index(row, k, N);
 }
 __device__ __forceinline__ size_t ubwd45_index(int gk, int hr, int N, int half_forms) {
-    return (half_forms & 2) ? ubwd5_index(gk, hr, N) : ubwd4_index(gk, hr, N);
+    return (half_forms & 4) ? ubwd6_index(gk, hr, N) : (half_forms & 2) ? ubwd5_index(gk, hr, N) : ubwd4_index(gk, hr, N);
 }
 __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, float4 *__restrict__ Ufwd,
                                                 float4 *__restrict__ Ubwd, float4 *__restrict__ Ubwd4,

@@ -117,7 +117,10 @@ struct lstm_hip_ctx {
     float4 *Ufwd4 = nullptr; // ... of the 8-column forward kernel (fwd_uses_8col_form) or, fwd_cols4, of the two-half one
     int n_cus = 0;           // compute units of the device (grid choices)
     bool side_stream = true; // LSTM_HIP_NO_SIDE_STREAM=1 (per handle): keep the whole window on one stream
+    int probe_overlap = 0;   // LSTM_HIP_PROBE_OVERLAP=k (per handle, timing probe): k Y-sized products on st2 beside the forward recurrence
     int bwd_halves = 0;      // 1: backward recurrence likewise (k_bwd_halves; LSTM_HIP_BWD_HALVES=1, unfused gradient sums)
+    bool bwd_scatter = false; // ... in its scatter form (k_bwd_scatter: partial sums scattered instead of dg gathered); the default
+    int half_forms() const { return fwd_cols4 | (bwd_halves ? (bwd_scatter ? 4 : 2) : 0); } // which U images are live (kernels.h)
     int fwd_cols4 = 0;       // 1: forward recurrence as two alternating 4-column halves per workgroup (k_fwd_persistent6)
     float *Hx = nullptr;     // 8-column forward form: ring of hand-off slots (data-as-flag), sentinel-filled
     int ring_base = 0;       // slot of step 0 in the next launch
@@ -283,13 +286,32 @@ int do_forward(lstm_hip_ctx *h) {
     const bool fast = (h->cfg.flags & LSTM_HIP_FAST_MATH) != 0;
     if (!h->packed && !h->bf16) { // (the bf16 path packs its own images, launch_fwd_recurrence)
         RUN(K_PACK_U, pack_U(h->P + h->pl.U, h->Ufwd4 ? nullptr : h->Ufwd, h->Ubwd4 ? nullptr : h->Ubwd, N, h->st, h->Ubwd4,
-                             h->Ufwd4, h->fwd_cols4 | (h->bwd_halves ? 2 : 0))); // one image per direction is live
+                             h->Ufwd4, h->half_forms())); // one image per direction is live
         h->packed = true;
     }
     h->n_dby_parts = softmax_parts(h->T);
+    // Timing probe (LSTM_HIP_PROBE_OVERLAP=1, tools/ab_kernels.py; results unaffected): the Y product of the PREVIOUS window's
+    // H is launched on st2 beside the forward recurrence, into the Pr buffer (overwritten by the softmax later), to measure
+    // what a time-batched product costs the recurrence when both share the chip ("overlap").
+    const int probe_overlap = h->probe_overlap;
+    if (probe_overlap && h->persistent && !h->bf16 && !h->profiling) {
+        HIP_TRY(hipEventRecord(h->ev_fork, h->st));
+        HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+    }
     if (h->persistent) {
         int rc = launch_fwd_recurrence(h);
         if (rc) return rc;
+        if (probe_overlap && !h->bf16 && !h->profiling) {
+            for (int rep = 0; rep < (probe_overlap & 15); rep++) {
+                if (probe_overlap & 16) // 64 x 64 tiles: can share a compute unit with a workgroup of the recurrence
+                    gemm_probe_small_kfast(256, h->T, N, h->P + h->pl.Why, 256, h->H + (size_t)N * B, N, h->Pr + (size_t)256 * B, 256, h->st2);
+                else // the library's 128 x 64 tiles (128 KB of LDS): starts only where a recurrence workgroup has left
+                    gemm(false, false, 256, h->T, N, h->P + h->pl.Why, 256, h->H + (size_t)N * B, N, h->Pr + (size_t)256 * B, 256, 1,
+                         nullptr, h->st2);
+            }
+            HIP_TRY(hipEventRecord(h->ev_join, h->st2));
+            HIP_TRY(hipStreamWaitEvent(h->st, h->ev_join, 0));
+        }
     } else {
         for (int t = 1; t < S; t++) {
             RUN(K_FWD_STEP, fwd_step(h->Ufwd, h->P + h->pl.W, h->P + h->pl.b, h->H + (size_t)(t - 1) * N * B,
@@ -353,6 +375,11 @@ int do_backward(lstm_hip_ctx *h) {
             RUN(K_BWD_PERSIST, bwd_persistent(reinterpret_cast<const float4 *>(h->Ubwd16), h->DG, h->DHy, h->G, h->C, h->H,
                                               h->xi, fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp,
                                               h->bwd_epoch, N, S, B, h->bwd_cols, h->st, nullptr, h->DGb));
+        } else if (h->bwd_halves && h->bwd_scatter) {
+            RUN(K_BWD_PERSIST, bwd_scatter(h->Ubwd4, h->DG, h->P + h->pl.Why, dY, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr,
+                                           h->DGx, cb, h->abortp, h->bwd_epoch, h->ring_base_b, N, S, B, h->bwd_halves >> 1, h->st,
+                                           h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr));
+            h->ring_base_b = bwds_ring_advance(h->ring_base_b, S);
         } else if (h->bwd_halves) {
             RUN(K_BWD_PERSIST, bwd_halves(h->Ubwd4, h->DG, h->P + h->pl.Why, dY, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr,
                                           h->DGx, cb, h->abortp, h->bwd_epoch, h->ring_base_b, N, S, B, h->bwd_halves >> 1, h->st,
@@ -502,12 +529,12 @@ int do_adagrad(lstm_hip_ctx *h, double lr) {
         RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
                                h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, h->gpart, NGb, bwd_partial_floats(h->cfg.N),
                                h->pl.by, h->n_slabs_dU > 0 ? h->slabs_dU : nullptr, h->n_slabs_dU,
-                               (size_t)4 * h->cfg.N * h->cfg.N, h->fwd_cols4 | (h->bwd_halves ? 2 : 0)));
+                               (size_t)4 * h->cfg.N * h->cfg.N, h->half_forms()));
     } else if (h->bf16) // the fp32 fragment images are not used by the bf16 path (its own are repacked by pack_U_bf16)
         RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, nullptr, nullptr, h->st));
     else
     RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
-                           h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, nullptr, 0, 0, 0, nullptr, 0, 0, h->fwd_cols4 | (h->bwd_halves ? 2 : 0)));
+                           h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, nullptr, 0, 0, 0, nullptr, 0, 0, h->half_forms()));
     h->packed = true; // the fp32 U images were refreshed by the same launch (the bf16 path has none)
     h->packed16 = false;
     h->why_packed = false;
@@ -660,7 +687,11 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
         // two-half form wherever it exists; "0" selects the one-recurrence form (A/B), other values are tuning bits (<< 1)
         const int bhv = bh ? atoi(bh) : 7; // 7: hint poll, no early request for half A (measured 347 us; 5 = no hint: 368)
         h->bwd_halves = bhv == 0 ? 0 : (bhv | 1) * (int)bwd_halves_supported((int)N, (int)B, prop.multiProcessorCount, want_fused);
-        if (h->bwd_halves) { // the two-half form hands dg over through a sentinel ring
+        // scatter form wherever the two-half form exists; LSTM_HIP_BWD_FORM=gather selects the latter (A/B; read per handle)
+        const char *bf = getenv("LSTM_HIP_BWD_FORM");
+        h->bwd_scatter = h->bwd_halves && !(bf && bf[0] == 'g') &&
+                         bwd_scatter_supported((int)N, (int)B, prop.multiProcessorCount, want_fused);
+        if (h->bwd_halves) { // both forms hand over through a sentinel ring
             ALLOC(h->DGx, bwd_ring_floats((int)N, (int)B));
             HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * bwd_ring_floats((int)N, (int)B)));
         }
@@ -676,6 +707,7 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     }
     if (h->persistent && want_fused && h->bwd_cols == 8)
         ALLOC(h->gpart, (size_t)((B + h->bwd_cols - 1) / h->bwd_cols) * bwd_partial_floats(cfg->N));
+    h->probe_overlap = getenv("LSTM_HIP_PROBE_OVERLAP") ? atoi(getenv("LSTM_HIP_PROBE_OVERLAP")) : 0;
     HIP_TRY(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));

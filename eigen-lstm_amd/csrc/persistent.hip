@@ -1819,6 +1819,321 @@ template <int N_, bool FUSE, bool STAMP = false> __global__ __launch_bounds__(BW
     else if (w == 11) bwdh_output_layer<N_, FUSE, STAMP>(p);
     else if (FUSE) bwdh_weight_sums<N_, FUSE, STAMP>(p);
 }
+
+// ------------------------------------------------------------------------------------------------
+// backward recurrence, SCATTER form (N = 512 / 256, 8-column groups, two alternating 4-column halves per workgroup): the
+// grid, side waves and LDS block of k_bwd_halves, but the recurrent product is split the other way round.
+//
+// dhnext = U^T dg_{t+1} contracts over the 4N gate rows and yields N values per column.  k_bwd_halves gives every workgroup
+// 16 OUTPUT units and lets it gather the whole dg_{t+1} (4N values per column: 32 KB per half and step, through a hint
+// poll and a second round trip, then a fold of 8 x 4 partial sums through LDS).  Here every workgroup keeps the 64 gate
+// rows IT PRODUCES (its 16 units x 4 gates) as its slice of the contraction -- the same slice of U the forward recurrence
+// holds -- and multiplies its own dg_t, straight from LDS, into partial sums for ALL N outputs; those are scattered to the
+// workgroups that own the outputs (64 values to each) and summed there, in source order, by the elementwise wave:
+//   product waves 0 .. N/64-1 : wave w owns outputs [64w, 64w+64), i.e. destination workgroups 4w .. 4w+3; v_mfma_f32_4x4x1,
+//        block = four outputs (lane = 4*block + j), CBSZ = 4 / ABID = ab: all sixteen blocks read dg[k = 4ab + r][column i]
+//        from block ab of ONE 16-byte LDS read; 64 instructions per half and step, weights Ubwd6 in 64 registers;
+//        a lane ends with the four columns of one output: one 16-byte store into the destination's ring slot.
+//        No K split over waves, so no partial-sum images, no counts, no fold.
+//   waves 8 / 9 (half A / B)  : poll the N/16 sources' 256-byte pieces of the slot (N/64 16-byte loads per lane, the data
+//        is the flag), sum them in source order (lane-local over every fourth source, then a 4 x 4 transpose-sum over the
+//        four 16-lane rows), do R/lstm.cc:228-247,256, hand dg_t to the product waves through LDS (1 KB) and store the
+//        plain DG off the chain.
+// Per half and step a workgroup now receives 8 KB instead of 32 KB, in one round trip instead of two, and the chain is
+//   partials stored -> L2 -> poll hit -> sum + elementwise -> LDS -> 64 matrix instructions -> partials stored.
+// Ring Qx[slot][group][half][destination][source][unit][column] (DGx buffer; bwd_ring_floats), data-as-flag as HX_RING:
+// P(t) (the product from dg_t, consumed by step t-1) writes slot(t) = (t + ring_base) & 3 for t = S-1 .. 2 and then resets
+// its own words of slot(t-2); the launch-to-launch advance is (ring_base - (S-2)) & 3 (tools/probes/ring_protocol_sim.py).
+//   * the reset is safe: a source holds ALL of Q_{t+1} before it computes Q_t, so every destination has finished the step
+//     that read Q_{t+2} (= slot(t-2));
+//   * a destination polls a source's words of slot(t-2) only after it consumed that source's Q_{t-1}, stored after an
+//     s_waitcnt vmcnt(0) that covers the reset: the reset is visible first.
+// The dg hand-off buffer is double-buffered by step parity: step t-2 overwrites it only after Q_{t-1} of every source is
+// in, each of which needed this workgroup's Q_t from every one of its product waves.
+// ------------------------------------------------------------------------------------------------
+#define SSTAMP(wave, k)                                                                                        \
+    if (STAMP && l == 0 && w == (wave) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && blockIdx.y == 0) \
+        stamps[((size_t)(blockIdx.x ? 1 : 0) * S + t) * 16 + (k)] = __builtin_amdgcn_s_memtime();
+__host__ __device__ inline size_t bwds_ring_floats(int N, int B) { return (size_t)HX_RING * ((B + 7) / 8) * 2 * (N / 16) * (N / 16) * 64; }
+
+template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_product(const BwdhArgs &p) {
+    BWDH_COMMON(p)
+    constexpr int NB = N / 16, NPW = N / 64; // sources / destinations per column group; product waves
+    float *dgl = red;                        // [half][step parity][column 4][k 64]: dg_t of this workgroup's own gate rows
+    unsigned *s_loc = sync_ + 12;            // [half]: the XCD-local publish was verified (set by the elementwise wave)
+    __builtin_amdgcn_s_setprio(2);           // below the elementwise waves (3), above the side waves 10 and 11 (0)
+    const bool active = w < NPW;
+    const int lb = l >> 2, lj = l & 3;
+    float4 a[16];
+#pragma unroll
+    for (int ab = 0; ab < 16; ab++) a[ab] = active ? Ubwd5[(((size_t)kb * NPW + w) * 16 + ab) * 64 + l] : float4{0.f, 0.f, 0.f, 0.f};
+    const int d = 4 * w + (lb >> 2), u = 4 * (lb & 3) + lj; // this lane's output: unit u of destination workgroup d
+    const __amdgpu_buffer_rsrc_t rQ = make_rsrc(DGx, bwds_ring_floats(N, B) * sizeof(float));
+    auto qoff = [&](int tt, int hf) { // float offset of this lane's 16 bytes in slot(tt)
+        const size_t slot = (size_t)((tt + ring_base) & (HX_RING - 1));
+        return ((((slot * NG + g) * 2 + hf) * NB + d) * NB + kb) * 64 + (size_t)u * 4;
+    };
+    bool live = true;
+    for (int t = S - 1; t >= 2 && live; t--) {
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            if (!live) break;
+            if (hf == 0) { SSTAMP(3, 8) }
+            // E(t) of this half has written dg_t: steps S-1 .. t of the parity of t, (S-1-t)/2 + 1 of them
+            if (!lds_wait(&s_done[2 * hf + (t & 1)], (unsigned)((S - 1 - t) / 2 + 1))) {
+                give_up();
+                live = false;
+                break;
+            }
+            if (hf == 0) { SSTAMP(3, 9) } else { SSTAMP(3, 5) }
+            if (active) {
+                const float4 dv = *reinterpret_cast<const float4 *>(dgl + (hf * 2 + (t & 1)) * 256 + lj * 64 + 4 * lb);
+                const bool local = t < S - 1 && __hip_atomic_load(&s_loc[hf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+#define S6(ab)                                                            \
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(dv.x, a[ab].x, c0, 4, ab, 0); \
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(dv.y, a[ab].y, c1, 4, ab, 0); \
+    c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(dv.z, a[ab].z, c2, 4, ab, 0); \
+    c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(dv.w, a[ab].w, c3, 4, ab, 0);
+                S6(0) S6(1) S6(2) S6(3) S6(4) S6(5) S6(6) S6(7) S6(8) S6(9) S6(10) S6(11) S6(12) S6(13) S6(14) S6(15)
+#undef S6
+                if (hf == 0) { SSTAMP(3, 10) } else { SSTAMP(3, 6) }
+                float4 q; // register r = column r of the half
+                q.x = hx_canon((c0[0] + c1[0]) + (c2[0] + c3[0]));
+                q.y = hx_canon((c0[1] + c1[1]) + (c2[1] + c3[1]));
+                q.z = hx_canon((c0[2] + c1[2]) + (c2[2] + c3[2]));
+                q.w = hx_canon((c0[3] + c1[3]) + (c2[3] + c3[3]));
+                const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
+                                     __uint_as_float(HX_SENT)};
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's older stores (the last reset) are complete
+                const size_t e_pub = qoff(t, hf), e_rst = qoff(t - 2, hf);
+                if (d < NB) { // (N = 256: every lane of an active wave has a destination; kept for clarity)
+                    if (XCD_LOCAL && local) {
+                        *reinterpret_cast<float4 *>(DGx + e_pub) = q;
+                        *reinterpret_cast<float4 *>(DGx + e_rst) = sent;
+                    } else {
+                        st_sc1(q, rQ, (int)(e_pub * sizeof(float)));
+                        st_sc1(sent, rQ, (int)(e_rst * sizeof(float)));
+                    }
+                }
+                if (hf == 0) { SSTAMP(3, 11) } else { SSTAMP(3, 7) }
+            }
+        }
+    }
+    if (FUSE) {
+        __syncthreads();
+        if (__hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return; // the host reports the abort
+        table_out();
+        __syncthreads();
+        if (w == 0) { // db partial: the eight columns in order
+            const int gt = l >> 4, rj = l & 15;
+            float sum = 0.0f;
+            for (int c = 0; c < 8; c++) sum += dbs[(c * 4 + gt) * 16 + rj];
+            base[(size_t)G4 * 256 + (size_t)G4 * N + gt * N + 16 * kb + rj] = sum;
+        }
+    }
+}
+template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_elementwise(const BwdhArgs &p) {
+    BWDH_COMMON(p)
+    constexpr int NB = N / 16, NLD = NB / 4; // sources per column group; 16-byte loads per lane and step
+    float *dgl = red;
+    unsigned *s_loc = sync_ + 12;
+    // ---------------- elementwise waves: wave 8 half A, wave 9 half B; lane = column*16 + unit ----------------
+    const int hf = w - 8;
+    __builtin_amdgcn_s_setprio(3);
+    const int cc = l >> 4, jj = l & 15;
+    const int ecol = 8 * g + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
+    const int j = 16 * kb + jj;
+    float dcn = 0.0f; // dcnext, R/lstm.cc:217
+    bool local_pub = false;
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rQ = make_rsrc(DGx, bwds_ring_floats(N, B) * sizeof(float));
+    // this lane's piece of a slot: sources 4i + (l >> 4), unit l & 15, the four columns
+    auto qbase = [&](int tt) {
+        const size_t slot = (size_t)((tt + ring_base) & (HX_RING - 1));
+        return (int)((((((slot * NG + g) * 2 + hf) * NB + kb) * NB + (size_t)(l >> 4)) * 64 + (size_t)(l & 15) * 4) * sizeof(float));
+    };
+    // operands that do not depend on the chain are requested a step ahead
+    float ig, og, fg, ug, cv, cp;
+    auto fetch = [&](int tu) {
+        const float *gc = G + ((size_t)tu * B + ecolc) * G4 + j;
+        ig = gc[0], og = gc[N], fg = gc[2 * N], ug = gc[3 * N];
+        cv = C[((size_t)tu * B + ecolc) * N + j], cp = C[((size_t)(tu - 1) * B + ecolc) * N + j];
+    };
+    fetch(S - 1);
+    float dhy = 0.0f;
+    const bool alive = lds_wait(s_ol, 1u);
+    if (alive) dhy = dhyb[((S - 1) & 3) * 128 + (4 * hf + cc) * 16 + jj];
+    else give_up();
+    for (int t = S - 1; t >= 1 && alive; t--) {
+        SSTAMP(8, 0)
+        float dhn = 0.0f;
+        if (t < S - 1) {
+            // Q_{t+1}: the partial sums every workgroup of the group computed from its dg_{t+1} for this workgroup's units
+            const int off = qbase(t + 1);
+            float4 v[NLD];
+            bool ok = false;
+            for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                bool gd = true;
+#pragma unroll
+                for (int i = 0; i < NLD; i++) v[i] = ld_sc1(rQ, off + i * (4 * 64 * (int)sizeof(float)));
+#pragma unroll
+                for (int i = 0; i < NLD; i++) gd = gd && hx_ready(v[i]);
+                if (__all(gd)) {
+                    ok = true;
+                    break;
+                }
+                if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            }
+            if (!ok) {
+                give_up();
+                break;
+            }
+            SSTAMP(8, 1)
+            // sum over the sources: lane-local over sources 4i + q (ascending i), then over the four rows q of 16 lanes
+            float4 sm = v[0];
+#pragma unroll
+            for (int i = 1; i < NLD; i++) {
+                sm.x += v[i].x;
+                sm.y += v[i].y;
+                sm.z += v[i].z;
+                sm.w += v[i].w;
+            }
+            // 4 x 4 transpose-sum: row q = l >> 4 needs column q.  Round 1 (partner row q ^ 1): keep the columns of q's
+            // parity, send the other two; round 2 (partner row q ^ 2): keep column q, send the other.
+            const int q = l >> 4;
+            const float k0 = (q & 1) ? sm.y : sm.x, k1 = (q & 1) ? sm.w : sm.z;   // columns (q & 1), (q & 1) + 2
+            const float s0 = (q & 1) ? sm.x : sm.y, s1 = (q & 1) ? sm.z : sm.w;   // the partner's
+            const float z0 = k0 + __shfl_xor(s0, 16, 64), z1 = k1 + __shfl_xor(s1, 16, 64);
+            const float keep = (q & 2) ? z1 : z0, send = (q & 2) ? z0 : z1;
+            dhn = keep + __shfl_xor(send, 32, 64);
+        }
+        // (dhy: the output-layer term of this step, picked up from wave 11's buffer a step ago, off the chain)
+        if (XCD_LOCAL && t == S - 2) { // every workgroup of the group has published Q_{S-1}, its XCC id before it
+            unsigned mine = 0;
+            bool same = true;
+            if (l < NBK) {
+                mine = __hip_atomic_load(xcc_tab + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                same = (mine >> 4) == epoch;
+            }
+            const unsigned first = __builtin_amdgcn_readfirstlane(mine);
+            if (l < NBK) same = same && mine == first;
+            local_pub = (XCD_FORCE_LOCAL || __all(same)) && NBK <= 64;
+            if (l == 0) __hip_atomic_store(&s_loc[hf], local_pub ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const float dh = dhy + dhn;                         // R/lstm.cc:228
+        float dcv = dh * og + dcn;                          // :233
+        dcv = dcv * (1.0f - cv * cv);                       // :235
+        const float d_o = (dh * cv) * (og * (1.0f - og));   // :238,244
+        const float d_i = (dcv * ug) * (ig * (1.0f - ig));  // :239,244
+        const float d_f = (dcv * cp) * (fg * (1.0f - fg));  // :240,244
+        const float d_u = (dcv * ig) * (1.0f - ug * ug);    // :241,247
+        dcn = dcv * fg;                                     // :256
+        SSTAMP(8, 2)
+        // dg_t for this workgroup's product waves: [column][k = gate*16 + unit], then the count (LDS operations of a wave
+        // execute in order: the count lands behind the values)
+        {
+            float *dp = dgl + (hf * 2 + (t & 1)) * 256 + cc * 64 + jj;
+            dp[0] = d_i;
+            dp[16] = d_o;
+            dp[32] = d_f;
+            dp[48] = d_u;
+            asm volatile("" ::: "memory");
+            if (l == 0) __hip_atomic_fetch_add(&s_done[2 * hf + (t & 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        SSTAMP(8, 3)
+        // off the chain: the plain DG the dU product reads after the launch.  4x4 transpose over the four lanes of a quad by
+        // DPP: lane (column cc, unit jj = 4*tq + ta) ends up with gate ta of units 4*tq .. 4*tq+3, one 16-byte store
+        const int ta = jj & 3, tq = jj >> 2;
+        float t0 = d_i, t1 = d_o, t2 = d_f, t3 = d_u;
+        {
+            const float lo = (ta & 1) ? t0 : t1, hi = (ta & 1) ? t2 : t3;
+            const float rlo = dpp_f<0xB1>(lo), rhi = dpp_f<0xB1>(hi); // quad_perm [1,0,3,2]
+            if (ta & 1) {
+                t0 = rlo;
+                t2 = rhi;
+            } else {
+                t1 = rlo;
+                t3 = rhi;
+            }
+            const float s0 = (ta & 2) ? t0 : t2, s1 = (ta & 2) ? t1 : t3;
+            const float r0 = dpp_f<0x4E>(s0), r1 = dpp_f<0x4E>(s1); // quad_perm [2,3,0,1]
+            if (ta & 2) {
+                t0 = r0;
+                t1 = r1;
+            } else {
+                t2 = r0;
+                t3 = r1;
+            }
+        }
+        if (ecol < B) {
+            const float4 v = {t0, t1, t2, t3};
+            *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
+        }
+        SSTAMP(8, 4)
+        if (t >= 2) {
+            fetch(t - 1);
+            // wave 11 runs up to four steps ahead of the chain, so this does not wait in practice
+            if (!lds_wait(s_ol, (unsigned)(S - (t - 1)))) {
+                give_up();
+                break;
+            }
+            dhy = dhyb[((t - 1) & 3) * 128 + (4 * hf + cc) * 16 + jj];
+        }
+        if (FUSE) {
+            if (ecol < B) { // db += dg, R/lstm.cc:252
+                dbacc[0] += d_i;
+                dbacc[1] += d_o;
+                dbacc[2] += d_f;
+                dbacc[3] += d_u;
+            }
+            // dg_t for the dW wave (four copies deep; s_tab counts the steps that wave has finished)
+            if (t + 4 <= S - 1 && !(cfg & 32) && !lds_wait(s_tab, (unsigned)(S - (t + 4)))) {
+                give_up();
+                break;
+            }
+            float *sp = stage + (hf * 4 + (t & 3)) * 256 + cc * 64 + jj;
+            sp[0] = d_i;
+            sp[16] = d_o;
+            sp[32] = d_f;
+            sp[48] = d_u;
+            asm volatile("" ::: "memory");
+        }
+        // step t done here: its dhy slot is free, its dg copy is in place
+        if (l == 0) __hip_atomic_fetch_add(&s_stage[hf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (FUSE) {
+        __syncthreads();
+        if (__hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++) dbs[((4 * hf + cc) * 4 + gt) * 16 + jj] = dbacc[gt]; // through `red` (free now)
+        __syncthreads();
+    }
+}
+template <int N_, bool FUSE, bool STAMP = false> __global__ __launch_bounds__(BWDH_THREADS) void k_bwd_scatter(const BwdhArgs p) {
+    BWDH_COMMON(p)
+    if (tid == 0) {
+        *s_abort = 0;
+        s_done[0] = s_done[1] = s_done[2] = s_done[3] = 0;
+        s_stage[0] = s_stage[1] = 0;
+        *s_dy = *s_ol = 0;
+        *s_tab = 0;
+        sync_[12] = sync_[13] = 0;
+        if (XCD_LOCAL) {
+            __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // visible before anything this workgroup publishes
+        }
+    }
+    if (FUSE)
+        for (int i = tid; i < 257 * 64; i += BWDH_THREADS) dWt[i] = 0.0f;
+    __syncthreads();
+    if (w < 8) bwds_product<N_, FUSE, STAMP>(p);
+    else if (w < 10) bwds_elementwise<N_, FUSE, STAMP>(p);
+    else if (w == 11) bwdh_output_layer<N_, FUSE, STAMP>(p);
+    else if (FUSE) bwdh_weight_sums<N_, FUSE, STAMP>(p);
+}
+#undef SSTAMP
 #undef HSTAMP
 
 // ------------------------------------------------------------------------------------------------
@@ -2558,8 +2873,53 @@ void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, 
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------------
-size_t bwd_ring_floats(int N, int B) { return (size_t)HX_RING * 4 * N * B; }
+// (one buffer serves whichever form the handle runs: the dg ring of the two-half form or the partial-sum ring of the scatter form)
+size_t bwd_ring_floats(int N, int B) {
+    const size_t dg = (size_t)HX_RING * 4 * N * B, q = (N == 512 || N == 256) ? bwds_ring_floats(N, B) : 0;
+    return dg > q ? dg : q;
+}
 int bwd_ring_advance(int ring_base, int S) { return (ring_base - (S - 1)) & (HX_RING - 1); }
+int bwds_ring_advance(int ring_base, int S) { return (ring_base - (S - 2)) & (HX_RING - 1); }
+
+// scatter form of the backward recurrence (k_bwd_scatter): the shapes of the two-half form
+bool bwd_scatter_supported(int N, int B, int n_cus, bool fused) {
+    if ((N != 512 && N != 256) || bwd_group_cols(N, B, n_cus) != 8) return false;
+    const size_t grid = (size_t)(N / 16) * ((B + 7) / 8);
+    int per_cu = 0;
+    if (N == 512)
+        per_cu = fused ? blocks_per_cu(k_bwd_scatter<512, true>, BWDH_THREADS, bwdh_lds_bytes(true))
+                       : blocks_per_cu(k_bwd_scatter<512, false>, BWDH_THREADS, bwdh_lds_bytes(false));
+    else
+        per_cu = fused ? blocks_per_cu(k_bwd_scatter<256, true>, BWDH_THREADS, bwdh_lds_bytes(true))
+                       : blocks_per_cu(k_bwd_scatter<256, false>, BWDH_THREADS, bwdh_lds_bytes(false));
+    return per_cu >= 1 && grid <= (size_t)n_cus;
+}
+void bwd_scatter(const float4 *Ubwd6, float *DG, const float *Why, const float *dY, const float *G, const float *C, const float *H,
+                 const int32_t *xi, float *gpart, float *Qx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N,
+                 int S, int B, int cfg, hipStream_t st, unsigned long long *stamps) {
+    const dim3 grid(N / 16, (B + 7) / 8), block(BWDH_THREADS);
+    const bool fuse = gpart != nullptr;
+    const size_t lds = bwdh_lds_bytes(fuse);
+#define BS_GO(...)                                                                                                                   \
+    do {                                                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_scatter<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds);                                                                                         \
+        hipLaunchKernelGGL((k_bwd_scatter<__VA_ARGS__>), grid, block, lds, st, args);                                                \
+    } while (0)
+    const BwdhArgs args = {Ubwd6, DG, Why, dY, G, C, H, xi, gpart, Qx, cnt, abortp, epoch, ring_base, S, B, cfg,
+                           N == 512 ? stamps : nullptr};
+    if (N == 256) {
+        if (fuse) BS_GO(256, true, false);
+        else BS_GO(256, false, false);
+    } else if (stamps != nullptr) {
+        if (fuse) BS_GO(512, true, true);
+        else BS_GO(512, false, true);
+    } else if (fuse)
+        BS_GO(512, true, false);
+    else
+        BS_GO(512, false, false);
+#undef BS_GO
+}
 
 // two-half form of the backward recurrence (k_bwd_halves): N = 512, 8-column groups
 bool bwd_halves_supported(int N, int B, int n_cus, bool fused) {

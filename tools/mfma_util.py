@@ -13,9 +13,9 @@ import json
 import sys
 from collections import defaultdict
 
-NAMES = {"k_bwd_persistent": "bwd_persistent", "k_bwd_halves": "bwd_persistent", "k_fwd_persistent": "fwd_persistent", "k_gemm<false, true": "gemm_dU",
-         "k_gemm<false, false": "gemm_Y", "Cijk_Ailk_Bljk": "gemm_Y", "Cijk_Ailk_Bjlk": "gemm_dU"}
-OUT = sys.argv[2] if len(sys.argv) > 2 else "profiles/r2_mfma_util.json"
+NAMES = {"k_bwd_persistent": "bwd_persistent", "k_bwd_halves": "bwd_persistent", "k_fwd_persistent": "fwd_persistent",
+         "k_gemm_regs<false, false": "gemm_dU", "k_gemm_regs<false, true": "gemm_Y"}
+OUT = sys.argv[2] if len(sys.argv) > 2 else "profiles/r3_mfma_util.json"
 acc = defaultdict(lambda: defaultdict(list))
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
@@ -24,7 +24,7 @@ with open(sys.argv[1]) as f:
                 acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 acc[short]["dur"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 out = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on `bench.py --steps 10 --warmup 3`, "
-                 "MI355X, round 2 kernels; per-launch means",
+                 "MI355X, round 3 kernels; per-launch means",
        "notes": "SQ_VALU_MFMA_BUSY_CYCLES is summed over all 1024 SIMDs (check: gemm_dU = 3.244M MFMA 32x32x2 x 64 cycles = "
                 "207.6M exactly); GRBM_GUI_ACTIVE is summed over the 8 XCDs; utilisation = busy / (1024 * GUI_ACTIVE/8)",
        "kernels": {}}
