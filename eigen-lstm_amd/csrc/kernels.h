@@ -66,16 +66,11 @@ bool fwd_uses_two_half_form(int N, int B, int n_cus);
 void fwd_persistent6(const float4 *Ufwd5, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
                      int poll_cfg, hipStream_t st, unsigned long long *stamps = nullptr);
-// two-half form of the backward recurrence (N = 512, 8-column groups): Ubwd5 image (pack_U / adagrad with bit 1 of
-// half_forms), dg ring DGx as for the data-as-flag hand-off; computes Why^T dy itself; gpart != null: fused mode as below
-bool bwd_halves_supported(int N, int B, int n_cus, bool fused);
-void bwd_halves(const float4 *Ubwd5, float *DG, const float *Why, const float *dY, const float *G, const float *C, const float *H,
-                const int32_t *xi, float *gpart, float *DGx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N,
-                int S, int B, int cfg, hipStream_t st, unsigned long long *stamps = nullptr);
-// scatter form of the backward recurrence (N = 512 / 256, 8-column groups; the default where it exists): every workgroup
-// multiplies its OWN dg_t into partial sums for all N outputs and scatters them to the owners of the outputs, instead of
-// gathering all of dg_{t+1}.  Ubwd6 image (pack_U / adagrad with bit 2 of half_forms), partial-sum ring Qx (bwd_ring_floats
-// floats, sentinel-filled like the other rings; ring_base moves by bwds_ring_advance).  Arguments otherwise as bwd_halves.
+// two-half (scatter) form of the backward recurrence (N = 512 / 256, 8-column groups): every workgroup advances its eight
+// columns as two alternating 4-column recurrences, multiplies its OWN dg_t into partial sums for all N outputs and scatters
+// them to the owners of the outputs.  Ubwd6 image (pack_U / adagrad with bit 2 of half_forms), partial-sum ring Qx
+// (bwd_ring_floats floats, sentinel-filled like the other rings; ring_base moves by bwds_ring_advance); computes Why^T dy
+// itself; gpart != null: fused mode as below.  cfg: tuning / test bits (16: keep the dispatch-order workgroup mapping).
 bool bwd_scatter_supported(int N, int B, int n_cus, bool fused);
 int bwds_ring_advance(int ring_base, int S);
 void bwd_scatter(const float4 *Ubwd6, float *DG, const float *Why, const float *dY, const float *G, const float *C, const float *H,

@@ -70,17 +70,6 @@ __device__ __forceinline__ size_t ufwd5_index(int row, int k, int N) { // float 
     const int l = 4 * (u & 15) + gate;
     return ((((size_t)(u >> 4) * 8 + w) * (Kw / 4) + (kk >> 2)) * 64 + l) * 4 + (kk & 3);
 }
-//   Ubwd5[kb][w][m][r][l].z' (the 4-column-half form of the backward recurrence, k_bwd_halves; stored through the Ubwd4
-//        pointer when bit 1 of `half_forms` is set): wave w of workgroup kb owns the gate rows of hidden units
-//        [UW*w, UW*(w+1)), UW = N/8 -- all four gates of a few producers, not one gate of many: a wave then waits for UW/16
-//        producer workgroups instead of N/32 -- in the order q = gate*UW + (unit - UW*w); lane l = 16Y + 4z + j;
-//        = U[row(q = 64m + 16Y + 4z' + r)][16*kb + 4z + j],  row(q) = (q / UW)*N + UW*w + q % UW
-__device__ __forceinline__ size_t ubwd5_index(int gk, int hr, int N) { // float index of U[gk][hr] in Ubwd5
-    const int UW = N / 8, gate = gk / N, unit = gk % N, w = unit / UW, q = gate * UW + unit % UW;
-    const int m = q >> 6, rem = q & 63;
-    const int Y = rem >> 4, zp = (rem >> 2) & 3, r = rem & 3, l = 16 * Y + (hr & 15);
-    return ((((((size_t)(hr >> 4) * 8 + w) * (N / 128) + m) * 4 + r) * 64 + l) * 4) + zp;
-}
 //   Ubwd6[kb][w][ab][l].r (the scatter form of the backward recurrence, k_bwd_scatter; stored through the Ubwd4 pointer when
 //        bit 2 of `half_forms` is set): workgroup kb keeps the 64 gate rows of ITS units, k = gate*16 + (unit - 16*kb) = 4*ab + r,
 //        for all N outputs: wave w owns outputs [64w, 64w+64), lane l = 4*block + j is output 64w + l;
@@ -90,12 +79,12 @@ __device__ __forceinline__ size_t ubwd6_index(int gk, int hr, int N) { // float 
     const int w = hr >> 6, l = hr & 63;
     return ((((size_t)kb * (N / 64) + w) * 16 + (kk >> 2)) * 64 + l) * 4 + (kk & 3);
 }
-// half_forms: bit 0 = the forward image is Ufwd5, bit 1 = the backward image is Ubwd5, bit 2 = the backward image is Ubwd6
+// half_forms: bit 0 = the forward image is Ufwd5, bit 2 = the backward image is Ubwd6 (bit 1: a removed form)
 __device__ __forceinline__ size_t ufwd45_index(int row, int k, int N, int half_forms) {
     return (half_forms & 1) ? ufwd5_index(row, k, N) : ufwd4_index(row, k, N);
 }
 __device__ __forceinline__ size_t ubwd45_index(int gk, int hr, int N, int half_forms) {
-    return (half_forms & 4) ? ubwd6_index(gk, hr, N) : (half_forms & 2) ? ubwd5_index(gk, hr, N) : ubwd4_index(gk, hr, N);
+    return (half_forms & 4) ? ubwd6_index(gk, hr, N) : ubwd4_index(gk, hr, N);
 }
 __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, float4 *__restrict__ Ufwd,
                                                 float4 *__restrict__ Ubwd, float4 *__restrict__ Ubwd4,

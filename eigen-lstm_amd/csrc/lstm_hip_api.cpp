@@ -118,9 +118,8 @@ struct lstm_hip_ctx {
     int n_cus = 0;           // compute units of the device (grid choices)
     bool side_stream = true; // LSTM_HIP_NO_SIDE_STREAM=1 (per handle): keep the whole window on one stream
     int probe_overlap = 0;   // LSTM_HIP_PROBE_OVERLAP=k (per handle, timing probe): k Y-sized products on st2 beside the forward recurrence
-    int bwd_halves = 0;      // 1: backward recurrence likewise (k_bwd_halves; LSTM_HIP_BWD_HALVES=1, unfused gradient sums)
-    bool bwd_scatter = false; // ... in its scatter form (k_bwd_scatter: partial sums scattered instead of dg gathered); the default
-    int half_forms() const { return fwd_cols4 | (bwd_halves ? (bwd_scatter ? 4 : 2) : 0); } // which U images are live (kernels.h)
+    int bwd_halves = 0;      // != 0: backward recurrence likewise, scatter form (k_bwd_scatter); bits above bit 0: its cfg word
+    int half_forms() const { return fwd_cols4 | (bwd_halves ? 4 : 0); } // which U images are live (kernels.h)
     int fwd_cols4 = 0;       // 1: forward recurrence as two alternating 4-column halves per workgroup (k_fwd_persistent6)
     float *Hx = nullptr;     // 8-column forward form: ring of hand-off slots (data-as-flag), sentinel-filled
     int ring_base = 0;       // slot of step 0 in the next launch
@@ -375,16 +374,11 @@ int do_backward(lstm_hip_ctx *h) {
             RUN(K_BWD_PERSIST, bwd_persistent(reinterpret_cast<const float4 *>(h->Ubwd16), h->DG, h->DHy, h->G, h->C, h->H,
                                               h->xi, fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp,
                                               h->bwd_epoch, N, S, B, h->bwd_cols, h->st, nullptr, h->DGb));
-        } else if (h->bwd_halves && h->bwd_scatter) {
+        } else if (h->bwd_halves) {
             RUN(K_BWD_PERSIST, bwd_scatter(h->Ubwd4, h->DG, h->P + h->pl.Why, dY, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr,
                                            h->DGx, cb, h->abortp, h->bwd_epoch, h->ring_base_b, N, S, B, h->bwd_halves >> 1, h->st,
                                            h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr));
             h->ring_base_b = bwds_ring_advance(h->ring_base_b, S);
-        } else if (h->bwd_halves) {
-            RUN(K_BWD_PERSIST, bwd_halves(h->Ubwd4, h->DG, h->P + h->pl.Why, dY, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr,
-                                          h->DGx, cb, h->abortp, h->bwd_epoch, h->ring_base_b, N, S, B, h->bwd_halves >> 1, h->st,
-                                          h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr));
-            h->ring_base_b = bwd_ring_advance(h->ring_base_b, S);
         } else {
             RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd4 ? h->Ubwd4 : h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi,
                                               fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp, h->bwd_epoch, N, S,
@@ -684,14 +678,11 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
         ALLOC(h->Ubwd4, N * N);
         const char *bh = getenv("LSTM_HIP_BWD_HALVES");
         h->side_stream = !(getenv("LSTM_HIP_NO_SIDE_STREAM") && atoi(getenv("LSTM_HIP_NO_SIDE_STREAM")));
-        // two-half form wherever it exists; "0" selects the one-recurrence form (A/B), other values are tuning bits (<< 1)
-        const int bhv = bh ? atoi(bh) : 7; // 7: hint poll, no early request for half A (measured 347 us; 5 = no hint: 368)
-        h->bwd_halves = bhv == 0 ? 0 : (bhv | 1) * (int)bwd_halves_supported((int)N, (int)B, prop.multiProcessorCount, want_fused);
-        // scatter form wherever the two-half form exists; LSTM_HIP_BWD_FORM=gather selects the latter (A/B; read per handle)
-        const char *bf = getenv("LSTM_HIP_BWD_FORM");
-        h->bwd_scatter = h->bwd_halves && !(bf && bf[0] == 'g') &&
-                         bwd_scatter_supported((int)N, (int)B, prop.multiProcessorCount, want_fused);
-        if (h->bwd_halves) { // both forms hand over through a sentinel ring
+        // two-half (scatter) form wherever it exists; "0" selects the one-recurrence form (A/B), other values carry test /
+        // tuning bits for the kernel (value >> 1 = its cfg word)
+        const int bhv = bh ? atoi(bh) : 1;
+        h->bwd_halves = bhv == 0 ? 0 : (bhv | 1) * (int)bwd_scatter_supported((int)N, (int)B, prop.multiProcessorCount, want_fused);
+        if (h->bwd_halves) { // hand-off through a sentinel ring
             ALLOC(h->DGx, bwd_ring_floats((int)N, (int)B));
             HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * bwd_ring_floats((int)N, (int)B)));
         }

@@ -14,8 +14,8 @@
 //             k_fwd_persistent4   N = 1024, 8-column groups: one recurrence per workgroup, same ring, one barrier
 //             k_fwd_persistent2   second form: 8 units x 16 columns on 16x16x4 tiles, counters   (small N, B <= 8, bf16 twin)
 //             k_fwd_persistent    first form: 4 units x 16 columns, counters                     (N = 64 multiples, bf16 twin)
-//   backward  k_bwd_halves        N = 512 / 256, 8-column groups: two alternating 4-column recurrences, side waves for the
-//                                 output-layer term and the dW / db / dWhy sums                           (the headline shape)
+//   backward  k_bwd_scatter       N = 512 / 256, 8-column groups: two alternating 4-column recurrences, partial sums scattered to
+//                                 the owners of the outputs; side waves for the output-layer term and the dW sums  (the headline shape)
 //             k_bwd_persistent    everything else: 16x16x4 tiles or 4x4x1 blocks, 4 / 8 / 16-column groups, fp32 or bf16,
 //                                 sharded counters, optional fused sums
 //
@@ -25,7 +25,7 @@
 // address.  A consumer's wave 0 polls the shards with sc1 loads until every shard has all its arrivals, a workgroup barrier
 // follows, and only then does any wave read h_t, with sc1 loads (never through L1).  Counters are never reset: launch number
 // e waits for e x arrivals.
-// Hand-off, data-as-flag form (k_fwd_persistent4 / 6, k_bwd_halves): see HX_RING below -- a ring of step slots whose words
+// Hand-off, data-as-flag form (k_fwd_persistent4 / 6, k_bwd_scatter): see HX_RING below -- a ring of step slots whose words
 // hold a sentinel until the value is stored; consumers re-issue the loads of their own K-slice until no word is the
 // sentinel.  No counters, no drain, no barrier ahead of the loads.
 // When a column group's workgroups are verified (per launch, HW_REG_XCC_ID) to sit on one XCD, the payload is published
@@ -63,6 +63,20 @@ template <bool FAST> __device__ __forceinline__ float p_tanh(float x) {
     if (FAST) return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
     const float e = p_exp_neg(2.0f * __builtin_fabsf(x));
     return __builtin_copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+}
+
+// the value of `v` in lane l ^ 16 / l ^ 32, on the vector ALU (v_permlane16_swap / v_permlane32_swap; a ds_bpermute through
+// the LDS crossbar costs ~10x the latency): both operands of the swap are v, so the odd rows / upper half find the partner's
+// value in the first result and the even rows / lower half in the second
+__device__ __forceinline__ float xchg_row16(float v, int l) {
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return __builtin_bit_cast(float, (l & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float xchg_half32(float v, int l) {
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return __builtin_bit_cast(float, (l & 32) ? r[0] : r[1]);
 }
 
 // DPP lane move (quad_perm / row shifts): the value of `v` in the lane the control word names; all lanes must be active
@@ -1225,30 +1239,18 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward recurrence, two half-groups per workgroup (N = 512, 8-column groups; the backward twin of k_fwd_persistent6).
-// grid (N/16, ceil(B/8)), 704 threads.  The eight columns of workgroup (kb, g) are two independent recurrences of four
-// columns, A and B: while A's dg_t is computed elementwise, published and fetched by the group, the eight product waves
-// run B's  dhnext = U^T dg_{t+1}  and the other way round.
-//   waves 0-7  product; K = 4N split over the waves BY HIDDEN UNIT: wave w takes all four gate rows of units
-//              [N/8*w, N/8*(w+1)), i.e. what N/128 producer workgroups publish (by gate it would be one gate of N/32
-//              producers: every wave would wait for half the group; 340 -> 335 us).  v_mfma_f32_4x4x1 with block = 4Y + z:
-//                D[i][j] += dg[row(q = 64m + 16Y + 4z' + r)][column 4*half + i] * U^T[unit 4z + j][row(q)]
-//              CBSZ = 2 / ABID = z': the four z-blocks of a Y-group read their dg from block z' of the loaded register,
-//              so a lane's 16-byte load m (lane = 16Y + 4z' + i: 16 consecutive bytes of k, 256 per column) feeds
-//              sixteen instructions; weights Ubwd5 (ubwd5_index), 64 registers; 64 instructions per half and step.
-//   wave 8 / 9 elementwise (R/lstm.cc:228-247,256) of half A / B: lane = column*16 + unit, folds the 8 x 4 (wave, Y)
-//              partial sums, publishes dg_t to the ring DGx (data-as-flag, as in the forward kernels) and stores
-//              the plain DG the dU product reads after the launch.  In the time it would otherwise wait for the next
-//              product it does the output-layer work of the NEXT step on the vector ALU (the matrix pipe belongs to the
-//              chain; the same work as 4x4x1 instructions in this wave measured +25 us a window):
-//                dhy_{t-1} = Why^T dy_{t-1}   (R/lstm.cc:228)   for its 16 units x 4 columns
-//                dWhy[:, units] += dy_{t-1} h_{t-1}^T (:226)    FUSE; 64 accumulators per lane
-//              as lane (m-quarter q, unit u): dy_{t-1} of the four columns is staged in LDS, Why[:, units] sits in LDS for
-//              the whole launch, each 16-byte LDS read of dy feeds 8 multiply-adds.
-//   wave 10    FUSE: dW[rows, x] += dg_t[rows, column] for the column's input byte x (R/lstm.cc:251): the [257][64] LDS
-//              table of k_bwd_persistent<.., FUSE>, fed through a double-buffered LDS copy of dg; db (:252) in the
-//              elementwise lanes' registers.  Partial blocks per column group go to gpart as there.
-// No workgroup barrier in the loop: LDS counters (s_done: partial sums in; s_stage / s_tab: dg copies for the dW wave).
+// backward recurrence, two half-groups per workgroup (N = 512 / 256, 8-column groups; the backward twin of
+// k_fwd_persistent6): grid (N/16, ceil(B/8)), 768 threads.  The eight columns of workgroup (kb, g) are two independent
+// recurrences of four columns, A and B, advanced alternately: while A's step is summed, computed elementwise and handed
+// on, the product waves work on B, and the other way round.  This part holds what the roles share -- arguments, the LDS
+// block, the two side waves -- the recurrence itself is k_bwd_scatter below.
+//   waves 0-7  product (bwds_product), and in FUSE mode dWhy[:, units] += dy_t h_t^T (R/lstm.cc:226) in their idle time
+//   wave 8 / 9 elementwise (R/lstm.cc:228-247,256) of half A / B (bwds_elementwise); db (:252) in their registers
+//   wave 10    FUSE: dW[rows, x] += dg_t[rows, column] for the column's input byte x (R/lstm.cc:251): a [257][64] LDS
+//              table fed through a four-deep LDS copy of dg.  Partial blocks per column group go to gpart.
+//   wave 11    the output-layer term dhy_t = Why^T dy_t (R/lstm.cc:228), up to four steps ahead of the chain
+// No workgroup barrier in the loop: LDS counters (s_done: dg_t handed to the product waves; s_stage / s_tab: dg copies for
+// the dW wave; s_ol: dhy ready).
 // ------------------------------------------------------------------------------------------------
 constexpr int BWDH_THREADS = 768;
 constexpr int BWDH_RED = 2 * 2 * 8 * 256, BWDH_YTMP = 256, BWDH_DHY = 4 * 128, BWDH_STAGE = 2 * 4 * 256;
@@ -1272,7 +1274,7 @@ struct BwdhArgs {
     int ring_base, S, B, cfg;
     unsigned long long *stamps;
 };
-constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -, s_stage[2], s_dy, s_ol, s_tab, s_done[2][2]
+constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -, s_stage[2], s_dy, s_ol, s_tab, s_done[2][2], s_loc[2], s_wy, consumed
 #define BWDH_COMMON(p)                                                                                                          \
     constexpr int N = N_, G4 = 4 * N, Kw = N / 2, NL = Kw / 64; /* NL 16-byte loads per lane, half and step */                  \
     static_assert(N == 512 || N == 256, "two-half backward form: hidden 512 or 256");                                           \
@@ -1330,7 +1332,8 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -
     float *base = FUSE ? gpart + (size_t)g * ((size_t)G4 * 256 + (size_t)G4 * N + G4 + (size_t)256 * N) : nullptr;              \
     float *dbs = red; /* epilogue scratch in `red` (free then): [column 0..7][gate][unit] */                                    \
     auto table_out = [&]() { /* dW partial: table row r = gate*16 + unit  ->  gradient row gate*N + 16*kb + unit */             \
-        const int pid = tid < 512 ? tid : tid - 128; /* the product waves and wave 10 (threads 640-703): 576 threads */         \
+        static_assert(BWDH_THREADS == 768, "roles: waves 0-7 product, 8-9 elementwise, 10 dW table, 11 output layer");            \
+        const int pid = tid < 512 ? tid : tid - 128; /* called by the product waves and wave 10 (threads 640-703): 576 threads */  \
         for (int i = pid; i < 256 * 64; i += 576) {                                                                             \
             const int x = i >> 6, r = i & 63;                                                                                   \
             base[(size_t)x * G4 + (r >> 4) * N + 16 * kb + (r & 15)] = dWt[i];                                                  \
@@ -1342,286 +1345,6 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -
         (void)ytmp, (void)dhyb, (void)stage, (void)dWt, (void)base, (void)dbs, (void)Kw, (void)NL, (void)WS,         \
         (void)kb, (void)w;
 
-template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_product(const BwdhArgs &p) {
-    BWDH_COMMON(p)
-    bool live = true; // false: this wave has left the loop on an abort
-    __builtin_amdgcn_s_setprio(2); // below the elementwise waves (3), above the side waves 10 and 11 (0)
-    // ---------------- product waves ----------------
-    const int lY = l >> 4, lz = (l >> 2) & 3, li = l & 3;
-    float4 a[4 * NL];
-#pragma unroll
-    for (int i = 0; i < 4 * NL; i++) a[i] = Ubwd5[(((size_t)kb * 8 + w) * (4 * NL) + i) * 64 + l];
-    // This wave's K-slice: the four gates of hidden units [UW*w, UW*(w+1)) -- UW/16 producer workgroups -- in the order
-    // q = gate*UW + unit; fragment m of lane (Y, z') is rows q = 64m + 16Y + 4z' .. +3 (ubwd5_index packs U to match)
-    constexpr int UW = N / 8;
-    int cofs[2], mofs[NL]; // float offsets inside a step slot: this lane's column, and its fragment m inside the column
-#pragma unroll
-    for (int hf = 0; hf < 2; hf++) {
-        const int c = 8 * g + 4 * hf + li, cc_ = c < B ? c : B - 1;
-        cofs[hf] = cc_ * G4;
-    }
-#pragma unroll
-    for (int m = 0; m < NL; m++) {
-        const int q = 64 * m + 16 * lY + 4 * lz;
-        mofs[m] = (q / UW) * N + UW * w + q % UW;
-    }
-    // hint: lane i < UW/16 looks at producer workgroup i of this wave's K-slice: the 16 bytes its elementwise wave stores
-    // from its last lane (column 3 of the half, gate 3, units 12-15)
-    const bool use_hint = (cfg & 1) != 0, spec_a = (cfg & 2) == 0;
-    const int hint_sleep = (cfg >> 8) ? (cfg >> 8) - 1 : 1; // pauses of 64 cycles between hint polls (tuning; default 1)
-    int hint_ofs[2];
-#pragma unroll
-    for (int hf = 0; hf < 2; hf++) {
-        const int c = 8 * g + 4 * hf + 3, cc_ = c < B ? c : B - 1;
-        hint_ofs[hf] = cc_ * G4 + 3 * N + UW * w + 16 * (l & (UW / 16 - 1)) + 12;
-    }
-    float4 bq[2][NL];
-    // (epilogue of this role: at the end of the branch)
-#pragma unroll
-    for (int hf = 0; hf < 2; hf++)
-#pragma unroll
-        for (int m = 0; m < NL; m++) bq[hf][m] = float4{0.f, 0.f, 0.f, 0.f};
-    // step t consumes dg_{t+1} from slot(t+1); the first product step is t = S-2.  Requests run one half-step ahead.
-    auto slot_off = [&](int tt, int hf) { return (int)(((size_t)((tt + ring_base) & (HX_RING - 1)) * B * G4 + cofs[hf]) * sizeof(float)); };
-    for (int t = S - 2; t >= 1 && live; t--) {
-#pragma unroll
-        for (int hf = 0; hf < 2; hf++) {
-            if (!live) break;
-            if (hf == 0) { HSTAMP(3, 8) }
-            bool good = (t < S - 2 && spec_a) || hf == 1; // (S-2, A) has not been requested yet
-            if (good)
-#pragma unroll
-                for (int m = 0; m < NL; m++) good = good && hx_ready(bq[hf][m]);
-            if (!__all(good)) {
-                const int off = slot_off(t + 1, hf);
-                if (use_hint) { // one request per wave until the last-stored piece of each producer of this K-slice is in
-                    const int hoff = (int)(((size_t)((t + 1 + ring_base) & (HX_RING - 1)) * B * G4 + hint_ofs[hf]) * sizeof(float));
-                    // (two hint requests in flight half a round trip apart: 360 us against 348 -- polls load the L2)
-                    for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
-                        float4 hv = {0.f, 0.f, 0.f, 0.f};
-                        if (l < UW / 16) hv = ld_sc1(rDG, hoff);
-                        if (__all(hx_ready(hv))) break;
-                        if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                        for (int i = 0; i < hint_sleep; i++) __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-                bool ok = false;
-                for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
-                    bool gd = true;
-#pragma unroll
-                    for (int m = 0; m < NL; m++) bq[hf][m] = ld_sc1(rDG, off + 4 * mofs[m]);
-#pragma unroll
-                    for (int m = 0; m < NL; m++) gd = gd && hx_ready(bq[hf][m]);
-                    if (__all(gd)) {
-                        ok = true;
-                        break;
-                    }
-                    if ((spins & 255) == 255 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                }
-                if (!ok) {
-                    give_up();
-                    live = false;
-                    break;
-                }
-            }
-            if (hf == 0) { HSTAMP(3, 9) } else { HSTAMP(3, 5) }
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
-#define H_STEP(av, wq)                                              \
-c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.x, c0, 2, 0, 0); \
-c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.y, c1, 2, 1, 0); \
-c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.z, c2, 2, 2, 0); \
-c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av, wq.w, c3, 2, 3, 0);
-#pragma unroll
-            for (int m = 0; m < NL; m++) {
-                H_STEP(bq[hf][m].x, a[4 * m + 0])
-                H_STEP(bq[hf][m].y, a[4 * m + 1])
-                H_STEP(bq[hf][m].z, a[4 * m + 2])
-                H_STEP(bq[hf][m].w, a[4 * m + 3])
-            }
-#undef H_STEP
-            __builtin_amdgcn_sched_barrier(0);
-            // the other half's next fragments: (t, B) behind A's product, (t-1, A) behind B's
-            {
-                const int tn = hf == 0 ? t : t - 1;
-                if (tn >= 1 && (hf == 0 || spec_a)) {
-                    const int noff = slot_off(tn + 1, hf ^ 1);
-#pragma unroll
-                    for (int m = 0; m < NL; m++) bq[hf ^ 1][m] = ld_sc1(rDG, noff + 4 * mofs[m]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (hf == 0) { HSTAMP(3, 10) } else { HSTAMP(3, 6) }
-            float *rp = red + (hf * 2 + (t & 1)) * (8 * WS) + w * WS + 4 * (4 * lz + li) + lY; // lane (Y, z, j = li): unit 4z + j
-#pragma unroll
-            for (int r = 0; r < 4; r++) rp[64 * r] = (c0[r] + c1[r]) + (c2[r] + c3[r]); // register r = column r of the half
-            asm volatile("" ::: "memory");
-            if (l == 0) __hip_atomic_fetch_add(&s_done[2 * hf + (t & 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (hf == 0) { HSTAMP(3, 11) } else { HSTAMP(3, 7) }
-        }
-    }
-    if (FUSE) {
-        __syncthreads();
-        if (__hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return; // the host reports the abort
-        table_out();
-        __syncthreads();
-        if (w == 0) { // db partial: the eight columns in order
-            const int gt = l >> 4, rj = l & 15;
-            float sum = 0.0f;
-            for (int c = 0; c < 8; c++) sum += dbs[(c * 4 + gt) * 16 + rj];
-            base[(size_t)G4 * 256 + (size_t)G4 * N + gt * N + 16 * kb + rj] = sum;
-        }
-    }
-}
-template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_elementwise(const BwdhArgs &p) {
-    BWDH_COMMON(p)
-    // ---------------- elementwise waves: wave 8 half A, wave 9 half B; lane = column*16 + unit ----------------
-    const int hf = w - 8;
-    __builtin_amdgcn_s_setprio(3);
-    const int cc = l >> 4, jj = l & 15;
-    const int ecol = 8 * g + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
-    const int j = 16 * kb + jj;
-    float dcn = 0.0f; // dcnext, R/lstm.cc:217
-    bool local_pub = false;
-    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
-    const float *rp0 = red + hf * 2 * (8 * WS) + 4 * (cc * 16 + jj);
-    // operands that do not depend on the chain are requested a step ahead
-    float ig, og, fg, ug, cv, cp;
-    auto fetch = [&](int tu) {
-        const float *gc = G + ((size_t)tu * B + ecolc) * G4 + j;
-        ig = gc[0], og = gc[N], fg = gc[2 * N], ug = gc[3 * N];
-        cv = C[((size_t)tu * B + ecolc) * N + j], cp = C[((size_t)(tu - 1) * B + ecolc) * N + j];
-    };
-    fetch(S - 1);
-    float dhy = 0.0f;
-    const bool alive = lds_wait(s_ol, 1u);
-    if (alive) dhy = dhyb[((S - 1) & 3) * 128 + (4 * hf + cc) * 16 + jj];
-    else give_up();
-    for (int t = S - 1; t >= 1 && alive; t--) {
-        HSTAMP(8, 0)
-        float dhn = 0.0f;
-        if (t < S - 1) {
-            // product steps S-2 .. t of the parity of t: (S - t) / 2 of them
-            if (!lds_wait(&s_done[2 * hf + (t & 1)], 8u * (unsigned)((S - t) / 2))) {
-                give_up();
-                break;
-            }
-            HSTAMP(8, 1)
-            const float *rp = rp0 + (t & 1) * (8 * WS);
-            float4 sm = *reinterpret_cast<const float4 *>(rp); // the four k-classes Y of a wave side by side
-#pragma unroll
-            for (int ww = 1; ww < 8; ww++) {
-                const float4 v = *reinterpret_cast<const float4 *>(rp + ww * WS);
-                sm.x += v.x;
-                sm.y += v.y;
-                sm.z += v.z;
-                sm.w += v.w;
-            }
-            dhn = (sm.x + sm.y) + (sm.z + sm.w);
-        }
-        // (dhy: the output-layer term of this step, picked up from wave 11's buffer a step ago, off the chain)
-        if (XCD_LOCAL && t == S - 2) { // every workgroup of the group has published dg_{S-1}, its XCC id before it
-            unsigned mine = 0;
-            bool same = true;
-            if (l < NBK) {
-                mine = __hip_atomic_load(xcc_tab + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                same = (mine >> 4) == epoch;
-            }
-            const unsigned first = __builtin_amdgcn_readfirstlane(mine);
-            if (l < NBK) same = same && mine == first;
-            local_pub = (XCD_FORCE_LOCAL || __all(same)) && NBK <= 64;
-        }
-        const float dh = dhy + dhn;                         // R/lstm.cc:228
-        float dcv = dh * og + dcn;                          // :233
-        dcv = dcv * (1.0f - cv * cv);                       // :235
-        const float d_o = (dh * cv) * (og * (1.0f - og));   // :238,244
-        const float d_i = (dcv * ug) * (ig * (1.0f - ig));  // :239,244
-        const float d_f = (dcv * cp) * (fg * (1.0f - fg));  // :240,244
-        const float d_u = (dcv * ig) * (1.0f - ug * ug);    // :241,247
-        dcn = dcv * fg;                                     // :256
-        // 4x4 transpose over the four lanes of a quad by DPP: lane (column cc, unit jj = 4*tq + ta) ends up with gate ta
-        // of units 4*tq .. 4*tq+3, one 16-byte store
-        const int ta = jj & 3, tq = jj >> 2;
-        float t0 = d_i, t1 = d_o, t2 = d_f, t3 = d_u;
-        {
-            const float lo = (ta & 1) ? t0 : t1, hi = (ta & 1) ? t2 : t3;
-            const float rlo = dpp_f<0xB1>(lo), rhi = dpp_f<0xB1>(hi); // quad_perm [1,0,3,2]
-            if (ta & 1) {
-                t0 = rlo;
-                t2 = rhi;
-            } else {
-                t1 = rlo;
-                t3 = rhi;
-            }
-            const float s0 = (ta & 2) ? t0 : t2, s1 = (ta & 2) ? t1 : t3;
-            const float r0 = dpp_f<0x4E>(s0), r1 = dpp_f<0x4E>(s1); // quad_perm [2,3,0,1]
-            if (ta & 2) {
-                t0 = r0;
-                t1 = r1;
-            } else {
-                t2 = r0;
-                t3 = r1;
-            }
-        }
-        HSTAMP(8, 2)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's older stores (the last reset) are complete
-        HSTAMP(8, 3)
-        if (ecol < B) {
-            const float4 v = {t0, t1, t2, t3};
-            const float4 vp = {hx_canon(v.x), hx_canon(v.y), hx_canon(v.z), hx_canon(v.w)};
-            const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
-                                 __uint_as_float(HX_SENT)};
-            const size_t within = (size_t)ecol * G4 + ta * N + 16 * kb + 4 * tq;
-            const size_t e_pub = (size_t)((t + ring_base) & (HX_RING - 1)) * B * G4 + within;
-            const size_t e_rst = (size_t)((t - 2 + ring_base) & (HX_RING - 1)) * B * G4 + within;
-            if (XCD_LOCAL && local_pub) {
-                *reinterpret_cast<float4 *>(DGx + e_pub) = vp;
-                *reinterpret_cast<float4 *>(DGx + e_rst) = sent;
-            } else {
-                st_sc1(vp, rDG, (int)(e_pub * sizeof(float)));
-                st_sc1(sent, rDG, (int)(e_rst * sizeof(float)));
-            }
-            *reinterpret_cast<float4 *>(DG + ((size_t)t * B + ecol) * G4 + ta * N + 16 * kb + 4 * tq) = v;
-        }
-        HSTAMP(8, 4)
-        if (t >= 2) {
-            fetch(t - 1);
-            // wave 11 runs up to four steps ahead of the chain, so this does not wait in practice
-            if (!lds_wait(s_ol, (unsigned)(S - (t - 1)))) {
-                give_up();
-                break;
-            }
-            dhy = dhyb[((t - 1) & 3) * 128 + (4 * hf + cc) * 16 + jj];
-        }
-        if (FUSE) {
-            if (ecol < B) { // db += dg, R/lstm.cc:252
-                dbacc[0] += d_i;
-                dbacc[1] += d_o;
-                dbacc[2] += d_f;
-                dbacc[3] += d_u;
-            }
-            // dg_t for the dW wave (four copies deep; s_tab counts the steps that wave has finished)
-            if (t + 4 <= S - 1 && !(cfg & 32) && !lds_wait(s_tab, (unsigned)(S - (t + 4)))) {
-                give_up();
-                break;
-            }
-            float *sp = stage + (hf * 4 + (t & 3)) * 256 + cc * 64 + jj;
-            sp[0] = d_i;
-            sp[16] = d_o;
-            sp[32] = d_f;
-            sp[48] = d_u;
-            asm volatile("" ::: "memory");
-        }
-        // step t done here: its dhy slot is free, its dg copy is in place
-        if (l == 0) __hip_atomic_fetch_add(&s_stage[hf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    if (FUSE) {
-        __syncthreads();
-        if (__hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
-#pragma unroll
-        for (int gt = 0; gt < 4; gt++) dbs[((4 * hf + cc) * 4 + gt) * 16 + jj] = dbacc[gt]; // through `red` (free now)
-        __syncthreads();
-    }
-}
 template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_output_layer(const BwdhArgs &p) {
     BWDH_COMMON(p)
     // ---------------- wave 11: the output-layer term dhy_t = Why^T dy_t (R/lstm.cc:228), ahead of the chain ----------------
@@ -1681,9 +1404,20 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_ou
         asm volatile("" ::: "memory");                                                                          \
         dst[64 * (hf) + l] = (v_.x + v_.y) + (v_.z + v_.w);                                                     \
     } while (0)
+    // FUSE: h_tu for the dWhy sums (lane l: unit l & 15 of columns l >> 4 and 4 + (l >> 4); zero for a padding column)
+    float hcur[2] = {0.f, 0.f}, hnext[2] = {0.f, 0.f};
+    auto h_request = [&](int tu) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int col = 8 * g + 4 * k + (l >> 4);
+            hnext[k] = col < B ? H[((size_t)tu * B + col) * N + 16 * kb + (l & 15)] : 0.0f;
+        }
+    };
     OL_REQUEST(S - 1);
+    if (FUSE) h_request(S - 1);
     for (int tu = S - 1; tu >= 1; tu--) {
         const int t = tu;
+        hcur[0] = hnext[0], hcur[1] = hnext[1];
         HSTAMP(11, 12)
         // slot tu & 3 held the term of step tu+4: both elementwise waves must have read it
         if (tu + 4 <= S - 1) {
@@ -1694,11 +1428,32 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_ou
             }
         }
         HSTAMP(11, 13)
+        if (FUSE) { // dy_tu and h_tu for the dWhy sums of the product waves (three-deep ring; sync_[15]: waves that have consumed)
+            if (tu + 3 <= S - 1 && !lds_wait(&sync_[15], 8u * (unsigned)(S - tu - 3))) {
+                give_up();
+                break;
+            }
+            float *sp = red + 1024 + (tu % 3) * (8 * 272) + 16 * lY + 4 * lz;
+            *reinterpret_cast<float4 *>(sp + li * 272) = a0;
+            *reinterpret_cast<float4 *>(sp + li * 272 + 64) = a1;
+            *reinterpret_cast<float4 *>(sp + li * 272 + 128) = a2;
+            *reinterpret_cast<float4 *>(sp + li * 272 + 192) = a3;
+            *reinterpret_cast<float4 *>(sp + (4 + li) * 272) = b0;
+            *reinterpret_cast<float4 *>(sp + (4 + li) * 272 + 64) = b1;
+            *reinterpret_cast<float4 *>(sp + (4 + li) * 272 + 128) = b2;
+            *reinterpret_cast<float4 *>(sp + (4 + li) * 272 + 192) = b3;
+            float *hp = red + 1024 + (tu % 3) * (8 * 272) + 256 + (l & 15);
+            hp[(l >> 4) * 272] = hcur[0];
+            hp[(4 + (l >> 4)) * 272] = hcur[1];
+            asm volatile("" ::: "memory");
+            if (l == 0) __hip_atomic_store(&sync_[14], (unsigned)(S - tu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         float *dst = dhyb + (tu & 3) * 128;
         OL_HALF(a0, a1, a2, a3, 0);
         OL_HALF(b0, b1, b2, b3, 1);
         HSTAMP(11, 14)
         if (tu >= 2) OL_REQUEST(tu - 1); // in flight until this wave comes round again
+        if (FUSE && tu >= 2) h_request(tu - 1);
         asm volatile("" ::: "memory");
         if (l == 0) __hip_atomic_store(s_ol, (unsigned)(S - tu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         HSTAMP(11, 15)
@@ -1713,26 +1468,8 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_ou
 }
 template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_weight_sums(const BwdhArgs &p) {
     BWDH_COMMON(p)
-    // ---------------- wave 10: the weight-gradient sums that stay in the workgroup ----------------
+    // ---------------- wave 10: the dW sums (the dWhy sums run in the product waves) ----------------
     //   dW[:, x] += dg_t[:, column]  (R/lstm.cc:251)  one lane per row (gate*16 + unit) of the workgroup, [257][64] LDS table
-    //   dWhy[:, units] += dy_t h_t^T (R/lstm.cc:226)  v_mfma_f32_4x4x1, one instruction = one column c, 64 output rows m and
-    //       four units: D[i][j] += h_t[unit 4q + i][c] * dy_t[m = 64mg + lane][c], the h operand broadcast from block q of a
-    //       register that holds the 16 units in lanes 0-15 (CBSZ = 4 / ABID = q); 16 accumulators (mg, q), 128 instructions
-    //       a step at the lowest priority; operands straight from global memory, a step ahead.
-    f32x4 acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float hq[8], dq[8][4]; // h_tu[unit l & 15][column c] (zero for a padding column: no dWhy from it), dy_tu[64mg + l][column c]
-    auto prefetch = [&](int tu) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const int col = 8 * g + c, colc = col < B ? col : B - 1;
-            hq[c] = col < B ? H[((size_t)tu * B + col) * N + 16 * kb + (l & 15)] : 0.0f;
-            const float *dp = dY + ((size_t)(tu - 1) * B + colc) * 256 + l; // dY holds steps 1.. at column (t-1)*B + b
-#pragma unroll
-            for (int mg = 0; mg < 4; mg++) dq[c][mg] = dp[64 * mg];
-        }
-    };
     // input bytes of the eight columns: lane c < 8 loads column c's, a step ahead (a vector load on purpose: scalar loads
     // share the LDS wait counter and would serialise with every LDS access below)
     auto xfetch = [&](int tu) -> int {
@@ -1741,24 +1478,9 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_we
         return x == -1 ? 256 : x; // -1: empty input column -> bucket 256; -2: padding column, skipped
     };
     int xnext = xfetch(S - 1);
-    prefetch(S - 1);
     for (int tu = S - 1; tu >= 1; tu--) {
         const int xcur = xnext;
         if (tu >= 2) xnext = xfetch(tu - 1);
-        if (!(cfg & 8)) {
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-#pragma unroll
-                for (int mg = 0; mg < 4; mg++) {
-                    acc[4 * mg + 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(hq[c], dq[c][mg], acc[4 * mg + 0], 4, 0, 0);
-                    acc[4 * mg + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(hq[c], dq[c][mg], acc[4 * mg + 1], 4, 1, 0);
-                    acc[4 * mg + 2] = __builtin_amdgcn_mfma_f32_4x4x1f32(hq[c], dq[c][mg], acc[4 * mg + 2], 4, 2, 0);
-                    acc[4 * mg + 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(hq[c], dq[c][mg], acc[4 * mg + 3], 4, 3, 0);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (tu >= 2) prefetch(tu - 1);
         bool ok = true;
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
@@ -1774,7 +1496,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_we
 #pragma unroll
             for (int c = 0; c < 4; c++) { // columns in order (two may share an input byte): deterministic sums
                 const int x = __builtin_amdgcn_readlane(xcur, 4 * hf + c);
-                if (x >= 0) dWt[x * 64 + l] += sv[c];
+                if (x >= 0) dWt[x * 64 + l] += sv[c]; // (as ds_add_f32 without return: 285 -> 307 us -- LDS float atomics hold the LDS up for the chain's waves)
             }
         }
         if (!ok) {
@@ -1787,49 +1509,20 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_we
     __syncthreads();
     if (__hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
     table_out();
-    // accumulator (mg, q): lane l = output row 64mg + l, register i = unit 4q + i
-    float *Yp = base + (size_t)G4 * 256 + (size_t)G4 * N + G4 + (size_t)(16 * kb) * 256 + l;
-#pragma unroll
-    for (int mg = 0; mg < 4; mg++)
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) Yp[(size_t)(4 * q + i) * 256 + 64 * mg] = acc[4 * mg + q][i];
     __syncthreads();
 }
-template <int N_, bool FUSE, bool STAMP = false> __global__ __launch_bounds__(BWDH_THREADS) void k_bwd_halves(const BwdhArgs p) {
-    BWDH_COMMON(p)
-    if (tid == 0) {
-        *s_abort = 0;
-        s_done[0] = s_done[1] = s_done[2] = s_done[3] = 0;
-        s_stage[0] = s_stage[1] = 0;
-        *s_dy = *s_ol = 0;
-        *s_tab = 0;
-        if (XCD_LOCAL) {
-            __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // visible before anything this workgroup publishes
-        }
-    }
-    if (FUSE)
-        for (int i = tid; i < 257 * 64; i += BWDH_THREADS) dWt[i] = 0.0f;
-    __syncthreads();
-    if (w < 8) bwdh_product<N_, FUSE, STAMP>(p);
-    else if (w < 10) bwdh_elementwise<N_, FUSE, STAMP>(p);
-    else if (w == 11) bwdh_output_layer<N_, FUSE, STAMP>(p);
-    else if (FUSE) bwdh_weight_sums<N_, FUSE, STAMP>(p);
-}
-
 // ------------------------------------------------------------------------------------------------
-// backward recurrence, SCATTER form (N = 512 / 256, 8-column groups, two alternating 4-column halves per workgroup): the
-// grid, side waves and LDS block of k_bwd_halves, but the recurrent product is split the other way round.
+// backward recurrence, SCATTER form (N = 512 / 256, 8-column groups, two alternating 4-column halves per workgroup).
 //
-// dhnext = U^T dg_{t+1} contracts over the 4N gate rows and yields N values per column.  k_bwd_halves gives every workgroup
-// 16 OUTPUT units and lets it gather the whole dg_{t+1} (4N values per column: 32 KB per half and step, through a hint
-// poll and a second round trip, then a fold of 8 x 4 partial sums through LDS).  Here every workgroup keeps the 64 gate
-// rows IT PRODUCES (its 16 units x 4 gates) as its slice of the contraction -- the same slice of U the forward recurrence
-// holds -- and multiplies its own dg_t, straight from LDS, into partial sums for ALL N outputs; those are scattered to the
-// workgroups that own the outputs (64 values to each) and summed there, in source order, by the elementwise wave:
+// dhnext = U^T dg_{t+1} contracts over the 4N gate rows and yields N values per column.  The forward recurrence gathers its
+// input (h: N values per column) and keeps its 64 output rows; doing the same here -- 16 OUTPUT units per workgroup, the
+// whole dg_{t+1} gathered -- means 4N values per column (32 KB per half and step), which rounds 1 and 2 fetched through a
+// hint poll and a second round trip and folded from 8 x 4 partial sums through LDS (336 us a window).  The backward
+// product is split the other way round: every workgroup keeps the 64 gate rows IT PRODUCES (its 16 units x 4 gates) as
+// its slice of the contraction -- the same slice of U the forward recurrence holds -- and multiplies its own dg_t,
+// straight from LDS, into partial sums for ALL N outputs; those are scattered to the workgroups that own the outputs (64
+// values to each) and summed there, in source order, by the elementwise wave (285 us with the side waves as they were,
+// 259 us with the dWhy sums moved into the product waves):
 //   product waves 0 .. N/64-1 : wave w owns outputs [64w, 64w+64), i.e. destination workgroups 4w .. 4w+3; v_mfma_f32_4x4x1,
 //        block = four outputs (lane = 4*block + j), CBSZ = 4 / ABID = ab: all sixteen blocks read dg[k = 4ab + r][column i]
 //        from block ab of ONE 16-byte LDS read; 64 instructions per half and step, weights Ubwd6 in 64 registers;
@@ -1867,11 +1560,60 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_pr
     float4 a[16];
 #pragma unroll
     for (int ab = 0; ab < 16; ab++) a[ab] = active ? Ubwd5[(((size_t)kb * NPW + w) * 16 + ab) * 64 + l] : float4{0.f, 0.f, 0.f, 0.f};
+    // The weights are complete in their registers before the loop starts: left to its own bookkeeping the compiler waits
+    // for them lazily INSIDE the loop with counted waits (vmcnt(23) .. vmcnt(8) between the matrix instructions), which
+    // from the second step on wait for whatever else is in flight -- the dWhy operand loads -- on the chain.
+#pragma unroll
+    for (int ab = 0; ab < 16; ab++) asm volatile("" ::"v"(a[ab].x), "v"(a[ab].y), "v"(a[ab].z), "v"(a[ab].w));
     const int d = 4 * w + (lb >> 2), u = 4 * (lb & 3) + lj; // this lane's output: unit u of destination workgroup d
     const __amdgpu_buffer_rsrc_t rQ = make_rsrc(DGx, bwds_ring_floats(N, B) * sizeof(float));
     auto qoff = [&](int tt, int hf) { // float offset of this lane's 16 bytes in slot(tt)
         const size_t slot = (size_t)((tt + ring_base) & (HX_RING - 1));
         return ((((slot * NG + g) * 2 + hf) * NB + d) * NB + kb) * 64 + (size_t)u * 4;
+    };
+    // FUSE: dWhy[:, units] += dy_t h_t^T (R/lstm.cc:226) between the products, while the wave would otherwise wait for the
+    // next hand-off.  v_mfma_f32_4x4x1, one instruction = one column c, 64 output rows (lane l = row 64mg + l) and four units:
+    // D[i][j] += h_t[unit 4q + i][c] * dy_t[row][c], the h operand broadcast from block q of a register that holds the 16
+    // units in lanes 0-15 (CBSZ = 4 / ABID = q).  The 16 accumulators (mg, q) are dealt two to a wave (mg = w >> 1,
+    // q = 2(w & 1), 2(w & 1) + 1): 16 instructions a step and wave, spread over all four SIMDs.  (As one side wave of 128
+    // instructions at the lowest priority they cost the chain 30 us a window: every matrix instruction of the two product
+    // waves on that SIMD queued behind one of them.)
+    const int wmg = w >> 1, wq0 = 2 * (w & 1);
+    f32x4 wacc0 = {0.f, 0.f, 0.f, 0.f}, wacc1 = wacc0;
+    // Operands: wave 11, which runs ahead of the chain and holds dy_tu in registers for its own product anyway, leaves dy_tu
+    // (8 columns x 256 rows) and h_tu (8 x 16 units) in a three-deep LDS ring; each product wave reads its rows from there.
+    // (Fetched by the product waves themselves -- 16 scalar loads a wave and step, 128 a workgroup -- the loads, not the
+    // matrix instructions, cost the chain 17 us a window: the chain's polls and stores queue behind them in the vector
+    // memory pipe.  Staged by wave 10, whose dW table work runs late at the lowest priority, the product waves waited for
+    // it: 300 us.)
+    float hq[8], dq[8]; // h_tu[unit l & 15][column c] (zero for a padding column: no dWhy from it), dy_tu[64 wmg + l][column c]
+    unsigned *s_wy = sync_ + 14;   // steps staged by wave 10 (S - tu); sync_[15]: product waves that have consumed, 8 a step
+    float *wyS = red + 1024;       // [step % 3][8 columns][256 rows | 16 units]: beside the dg hand-off buffers in `red`
+    auto wfetch = [&](int tu) -> bool {
+        if (!lds_wait(s_wy, (unsigned)(S - tu))) return false;
+        const float *sp = wyS + (tu % 3) * (8 * 272);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            dq[c] = sp[c * 272 + 64 * wmg + l];
+            hq[c] = sp[c * 272 + 256 + (l & 15)];
+        }
+        return true;
+    };
+    auto wrelease = [&]() {
+        asm volatile("" ::: "memory");
+        if (l == 0) __hip_atomic_fetch_add(&sync_[15], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wstep = [&]() {
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            if (wq0 == 0) {
+                wacc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(hq[c], dq[c], wacc0, 4, 0, 0);
+                wacc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(hq[c], dq[c], wacc1, 4, 1, 0);
+            } else {
+                wacc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(hq[c], dq[c], wacc0, 4, 2, 0);
+                wacc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(hq[c], dq[c], wacc1, 4, 3, 0);
+            }
+        }
     };
     bool live = true;
     for (int t = S - 1; t >= 2 && live; t--) {
@@ -1879,7 +1621,8 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_pr
         for (int hf = 0; hf < 2; hf++) {
             if (!live) break;
             if (hf == 0) { SSTAMP(3, 8) }
-            // E(t) of this half has written dg_t: steps S-1 .. t of the parity of t, (S-1-t)/2 + 1 of them
+            // E(t) of this half has written dg_t: steps S-1 .. t of the parity of t, (S-1-t)/2 + 1 of them.  (Spinning on the LDS
+            // word without lds_wait's 64-cycle pauses: 290 -> 303 us -- eight waves hammering the LDS slow the elementwise waves.)
             if (!lds_wait(&s_done[2 * hf + (t & 1)], (unsigned)((S - 1 - t) / 2 + 1))) {
                 give_up();
                 live = false;
@@ -1905,7 +1648,8 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_pr
                 q.w = hx_canon((c0[3] + c1[3]) + (c2[3] + c3[3]));
                 const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
                                      __uint_as_float(HX_SENT)};
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's older stores (the last reset) are complete
+                // this wave's older stores (the last reset) are complete
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const size_t e_pub = qoff(t, hf), e_rst = qoff(t - 2, hf);
                 if (d < NB) { // (N = 256: every lane of an active wave has a destination; kept for clarity)
                     if (XCD_LOCAL && local) {
@@ -1919,10 +1663,34 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_pr
                 if (hf == 0) { SSTAMP(3, 11) } else { SSTAMP(3, 7) }
             }
         }
+        if (FUSE && live) { // step t's share of dWhy, behind half B's product: the wave would wait for the next hand-off anyway
+            if (!wfetch(t)) {
+                give_up();
+                live = false;
+                break;
+            }
+            if (!(cfg & 8)) wstep();
+            wrelease();
+        }
+    }
+    if (FUSE && live) { // step 1 (or S - 1 = 1: the only step)
+        if (wfetch(1)) {
+            if (!(cfg & 8)) wstep();
+            wrelease();
+        } else
+            give_up();
     }
     if (FUSE) {
         __syncthreads();
         if (__hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return; // the host reports the abort
+        {   // accumulator (mg, q): lane l = output row 64mg + l, register i = unit 4q + i
+            float *Yp = base + (size_t)G4 * 256 + (size_t)G4 * N + G4 + (size_t)(16 * kb) * 256 + 64 * wmg + l;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                Yp[(size_t)(4 * wq0 + i) * 256] = wacc0[i];
+                Yp[(size_t)(4 * (wq0 + 1) + i) * 256] = wacc1[i];
+            }
+        }
         table_out();
         __syncthreads();
         if (w == 0) { // db partial: the eight columns in order
@@ -2004,9 +1772,9 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_el
             const int q = l >> 4;
             const float k0 = (q & 1) ? sm.y : sm.x, k1 = (q & 1) ? sm.w : sm.z;   // columns (q & 1), (q & 1) + 2
             const float s0 = (q & 1) ? sm.x : sm.y, s1 = (q & 1) ? sm.z : sm.w;   // the partner's
-            const float z0 = k0 + __shfl_xor(s0, 16, 64), z1 = k1 + __shfl_xor(s1, 16, 64);
+            const float z0 = k0 + xchg_row16(s0, l), z1 = k1 + xchg_row16(s1, l);
             const float keep = (q & 2) ? z1 : z0, send = (q & 2) ? z0 : z1;
-            dhn = keep + __shfl_xor(send, 32, 64);
+            dhn = keep + xchg_half32(send, l);
         }
         // (dhy: the output-layer term of this step, picked up from wave 11's buffer a step ago, off the chain)
         if (XCD_LOCAL && t == S - 2) { // every workgroup of the group has published Q_{S-1}, its XCC id before it
@@ -2118,7 +1886,7 @@ template <int N_, bool FUSE, bool STAMP = false> __global__ __launch_bounds__(BW
         s_stage[0] = s_stage[1] = 0;
         *s_dy = *s_ol = 0;
         *s_tab = 0;
-        sync_[12] = sync_[13] = 0;
+        sync_[12] = sync_[13] = sync_[14] = sync_[15] = 0;
         if (XCD_LOCAL) {
             __hip_atomic_store(xcc_tab + kb, (epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -2919,47 +2687,6 @@ void bwd_scatter(const float4 *Ubwd6, float *DG, const float *Why, const float *
     else
         BS_GO(512, false, false);
 #undef BS_GO
-}
-
-// two-half form of the backward recurrence (k_bwd_halves): N = 512, 8-column groups
-bool bwd_halves_supported(int N, int B, int n_cus, bool fused) {
-    if ((N != 512 && N != 256) || bwd_group_cols(N, B, n_cus) != 8) return false;
-    const size_t grid = (size_t)(N / 16) * ((B + 7) / 8);
-    int per_cu = 0;
-    if (N == 512)
-        per_cu = fused ? blocks_per_cu(k_bwd_halves<512, true>, BWDH_THREADS, bwdh_lds_bytes(true))
-                       : blocks_per_cu(k_bwd_halves<512, false>, BWDH_THREADS, bwdh_lds_bytes(false));
-    else
-        per_cu = fused ? blocks_per_cu(k_bwd_halves<256, true>, BWDH_THREADS, bwdh_lds_bytes(true))
-                       : blocks_per_cu(k_bwd_halves<256, false>, BWDH_THREADS, bwdh_lds_bytes(false));
-    return per_cu >= 1 && grid <= (size_t)n_cus;
-}
-void bwd_halves(const float4 *Ubwd5, float *DG, const float *Why, const float *dY, const float *G, const float *C, const float *H,
-                const int32_t *xi, float *gpart, float *DGx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N,
-                int S, int B, int cfg, hipStream_t st, unsigned long long *stamps) {
-    const dim3 grid(N / 16, (B + 7) / 8), block(BWDH_THREADS);
-    const bool fuse = gpart != nullptr;
-    const size_t lds = bwdh_lds_bytes(fuse);
-#define BH_GO(...)                                                                                                                  \
-    do {                                                                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd_halves<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)lds);                                                                                        \
-        hipLaunchKernelGGL((k_bwd_halves<__VA_ARGS__>), grid, block, lds, st, args);                                                \
-    } while (0)
-    const BwdhArgs args = {Ubwd5, DG, Why, dY, G, C, H, xi, gpart, DGx, cnt, abortp, epoch, ring_base, S, B, cfg, stamps};
-    if (N == 256) { // (stamped builds exist for the headline shape)
-        const BwdhArgs args256 = {Ubwd5, DG, Why, dY, G, C, H, xi, gpart, DGx, cnt, abortp, epoch, ring_base, S, B, cfg, nullptr};
-        const BwdhArgs &args = args256;
-        if (fuse) BH_GO(256, true, false);
-        else BH_GO(256, false, false);
-    } else if (stamps != nullptr) {
-        if (fuse) BH_GO(512, true, true);
-        else BH_GO(512, false, true);
-    } else if (fuse)
-        BH_GO(512, true, false);
-    else
-        BH_GO(512, false, false);
-#undef BH_GO
 }
 
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,

@@ -66,7 +66,39 @@ if os.environ.get("LSTM_HIP_FWD_HALVES", "1") != "0":   # two-half form: wave 3 
             ("half A published -> wave 3's next half-A poll complete", s[t + 1, 9] - s[t, 3]),
         ])
 
-if os.environ.get("LSTM_HIP_BWD_HALVES", "7") != "0":   # two-half backward form (the default)
+if os.environ.get("LSTM_HIP_BWD_HALVES", "7") != "0" and os.environ.get("LSTM_HIP_BWD_FORM", "s")[0] != "g":
+    # scatter form of the two-half backward recurrence (the default): wave 3 = a product wave, wave 8 = elementwise of half A
+    for wg in (2, 3):
+        s = st[wg]
+        t = np.arange(S - 5, 3, -1)
+        show(f"backward scatter form, workgroup {wg - 2}: {np.median(s[t - 1, 0] - s[t, 0]):.0f} cycles per step", [
+            ("elementwise wave 8: loop top -> partial sums of all sources in (poll)", s[t, 1] - s[t, 0]),
+            ("elementwise wave 8: sum over sources + transpose-sum + elementwise", s[t, 2] - s[t, 1]),
+            ("elementwise wave 8: dg_t to LDS + count", s[t, 3] - s[t, 2]),
+            ("elementwise wave 8: DPP transpose + plain DG store issued (off the chain)", s[t, 4] - s[t, 3]),
+            ("elementwise wave 8: operand prefetch, dhy pick-up, stage copy -> next loop top", s[t - 1, 0] - s[t, 4]),
+            ("product wave 3, half A: loop top -> dg_t in LDS (wait)", s[t, 9] - s[t, 8]),
+            ("product wave 3, half A: LDS read + 64 MFMA", s[t, 10] - s[t, 9]),
+            ("product wave 3, half A: s_waitcnt + partial sums stored + reset", s[t, 11] - s[t, 10]),
+            ("product wave 3, half B: wait", s[t, 5] - s[t, 11]),
+            ("product wave 3, half B: LDS read + 64 MFMA", s[t, 6] - s[t, 5]),
+            ("product wave 3, half B: stores", s[t, 7] - s[t, 6]),
+            ("chain: dg_t in LDS (wave 8) -> wave 3's partial sums stored", s[t, 11] - s[t, 3]),
+            ("chain: wave 3's partial sums stored -> next step's poll complete (hop + the other 31 sources)", s[t - 1, 1] - s[t, 11]),
+        ])
+    s = st[2]
+    t = np.arange(S - 6, 3, -1)
+    show("wave 11 (output layer ahead of the chain), workgroup 0", [
+        ("period (loop top to loop top)", s[t - 1, 12] - s[t, 12]),
+        ("wait for the slot (step t+4 consumed)", s[t, 13] - s[t, 12]),
+        ("128 instructions 4x4x1 + fold through LDS (needs last step's loads)", s[t, 14] - s[t, 13]),
+        ("next request + signal", s[t, 15] - s[t, 14]),
+        ("-> next loop top", s[t - 1, 12] - s[t, 15]),
+        ("lead over the elementwise wave: its step-t start minus this wave's", s[t, 0] - s[t, 12]),
+    ])
+    sys.exit(0)
+
+if os.environ.get("LSTM_HIP_BWD_HALVES", "7") != "0":   # two-half backward form, gather variant (LSTM_HIP_BWD_FORM=gather)
     for wg in (2, 3):
         s = st[wg]
         t = np.arange(S - 5, 3, -1)
