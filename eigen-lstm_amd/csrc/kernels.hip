@@ -99,10 +99,14 @@ __global__ __launch_bounds__(256) void k_pack_U(const float *__restrict__ U, flo
             const float4 p = *reinterpret_cast<const float4 *>(U + (size_t)k * G4 + r);
             float *u4 = reinterpret_cast<float *>(Ubwd4);
             if (Ubwd4 != nullptr) {
-                u4[ubwd45_index(r + 0, k, N, half_forms)] = p.x;
-                u4[ubwd45_index(r + 1, k, N, half_forms)] = p.y;
-                u4[ubwd45_index(r + 2, k, N, half_forms)] = p.z;
-                u4[ubwd45_index(r + 3, k, N, half_forms)] = p.w;
+                if (half_forms & 4) { // Ubwd6: four consecutive gate rows of one hidden column are one 16-byte piece of the image
+                    *reinterpret_cast<float4 *>(u4 + ubwd6_index(r, k, N)) = p;
+                } else {
+                    u4[ubwd45_index(r + 0, k, N, half_forms)] = p.x;
+                    u4[ubwd45_index(r + 1, k, N, half_forms)] = p.y;
+                    u4[ubwd45_index(r + 2, k, N, half_forms)] = p.z;
+                    u4[ubwd45_index(r + 3, k, N, half_forms)] = p.w;
+                }
             }
             if (Ufwd4 != nullptr) {
                 float *f4 = reinterpret_cast<float *>(Ufwd4);
@@ -1001,10 +1005,14 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *_
             if (Ubwd != nullptr) Ubwd[((size_t)(k >> 4) * (N / 4) + (r >> 4)) * 64 + (((r & 15) >> 2) << 4) + (k & 15)] = p;
             if (Ubwd4 != nullptr) {
                 float *u4 = reinterpret_cast<float *>(Ubwd4);
-                u4[ubwd45_index(r + 0, k, N, half_forms)] = p.x;
-                u4[ubwd45_index(r + 1, k, N, half_forms)] = p.y;
-                u4[ubwd45_index(r + 2, k, N, half_forms)] = p.z;
-                u4[ubwd45_index(r + 3, k, N, half_forms)] = p.w;
+                if (half_forms & 4) { // Ubwd6: four consecutive gate rows of one hidden column are one 16-byte piece of the image
+                    *reinterpret_cast<float4 *>(u4 + ubwd6_index(r, k, N)) = p;
+                } else {
+                    u4[ubwd45_index(r + 0, k, N, half_forms)] = p.x;
+                    u4[ubwd45_index(r + 1, k, N, half_forms)] = p.y;
+                    u4[ubwd45_index(r + 2, k, N, half_forms)] = p.z;
+                    u4[ubwd45_index(r + 3, k, N, half_forms)] = p.w;
+                }
             }
             if (Ufwd4 != nullptr) {
                 float *f4 = reinterpret_cast<float *>(Ufwd4);
