@@ -148,6 +148,8 @@ def main():
                          "within ~100 windows unless the class_CUDA warm-up (lr=0 for 50*S windows) is used")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--bf16", action="store_true", help="bf16 MFMA in the recurrent products (not the headline dtype)")
+    ap.add_argument("--fp32", action="store_true", help="force the fp32 path on a config whose named dtype is bf16 (configs[4]: the "
+                                                         "fp32 line beside the bf16 one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-windows", type=int, default=3)
     args = ap.parse_args()
@@ -164,7 +166,7 @@ def main():
     import lstm_hip
 
     cfg = CONFIGS[args.config]
-    if cfg.get("bf16"):
+    if cfg.get("bf16") and not args.fp32:
         args.bf16 = True
     if args.bf16:
         args.flags |= 128  # LSTM_HIP_BF16_RECURRENCE
