@@ -91,6 +91,14 @@ void pack_U_bf16(const float *U, void *Ufwd16, void *Ubwd16, int N, hipStream_t 
 void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, float *H, unsigned short *Hb, float *C,
                          float *G, const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
                          bool fast, hipStream_t st, int n_cus);
+// scatter form of the bf16 backward recurrence (N = 256 / 512 / 1024, 8-column groups co-resident): Ubwd6b image (pack_U6_bf16,
+// N*N*8 bytes), partial-sum ring Qx as in bwd_scatter; reads DHy (a launch of its own in the bf16 path), writes the fp32 DG
+bool bwd_scatter_bf16_supported(int N, int B, int n_cus);
+void pack_U6_bf16(const float *U, void *Ubwd6b, int N, hipStream_t st);
+size_t bwd_scatter_bf16_ring_floats(int N, int B);
+int bwd_scatter_bf16_ring_advance(int base, int S);
+void bwd_scatter_bf16(const void *Ubwd6b, float *DG, const float *DHy, const float *G, const float *C, float *Qx, unsigned *cnt,
+                      unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int n_cus, hipStream_t st);
 size_t bwd_partial_floats(int N);
 int bwd_group_cols(int N, int B, int n_cus); // 8 or 16 batch columns per backward workgroup
 

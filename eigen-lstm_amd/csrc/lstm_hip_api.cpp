@@ -103,6 +103,8 @@ struct lstm_hip_ctx {
     bool packed16 = false;
     unsigned short *Hb = nullptr, *DGb = nullptr; // bf16 hand-off copies of h and dg
     void *Ufwd16 = nullptr, *Ubwd16 = nullptr;    // bf16 fragment images of U
+    void *Ubwd6b = nullptr;                       // ... and the scatter-form backward's (bwd_scatter16)
+    bool bwd_scatter16 = false;                   // bf16 backward recurrence in its scatter form (k_bwd_scatter_bf16)
     // bf16 operands of the four time-batched products, k contiguous (kernels.h, gemm_bf16): Why^T and Why; per window
     // h^T [N][SBpad], dy^T [256][Tpad], dg^T [4N][Tpad] and dy [T][256]
     unsigned short *WhyT_b = nullptr, *Why_b = nullptr, *Ht_b = nullptr, *dYt_b = nullptr, *DGt_b = nullptr, *dYb = nullptr;
@@ -125,6 +127,7 @@ struct lstm_hip_ctx {
     int ring_base = 0;       // slot of step 0 in the next launch
     float *DGx = nullptr;    // backward recurrence: the same kind of ring for dg
     int ring_base_b = 0;
+    size_t DGx_floats = 0;   // size of the backward hand-off ring
     int poll_cfg = 0;        // LSTM_HIP_FWD_POLL: bits 0-7 s_sleep between polls, 8-15 first delay of the non-gating waves
     bool packed = false;
     float *H = nullptr, *C = nullptr, *G = nullptr, *DG = nullptr, *Y = nullptr, *Pr = nullptr, *DHy = nullptr;
@@ -232,7 +235,7 @@ int check_abort(lstm_hip_ctx *h) {
             h->ring_base = 0;
         }
         if (h->DGx) {
-            HIP_TRY(hipMemsetAsync(h->DGx, 0xff, sizeof(float) * bwd_ring_floats(h->cfg.N, h->cfg.B), h->st));
+            HIP_TRY(hipMemsetAsync(h->DGx, 0xff, sizeof(float) * h->DGx_floats, h->st));
             h->ring_base_b = 0;
         }
         return fail(LSTM_HIP_ESTATE, "a persistent recurrence kernel timed out waiting for a hand-off (results invalid)");
@@ -260,7 +263,8 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
     h->fwd_epoch++;
     if (h->bf16) {
         if (!h->packed16) {
-            RUN(K_PACK_U, pack_U_bf16(h->P + h->pl.U, h->Ufwd16, h->Ubwd16, N, h->st));
+            RUN(K_PACK_U, (pack_U_bf16(h->P + h->pl.U, h->Ufwd16, h->Ubwd16, N, h->st),
+                           h->bwd_scatter16 ? pack_U6_bf16(h->P + h->pl.U, h->Ubwd6b, N, h->st) : (void)0));
             h->packed16 = true;
         }
         RUN(K_FWD_PERSIST, fwd_persistent_bf16(h->Ufwd16, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi,
@@ -370,7 +374,11 @@ int do_backward(lstm_hip_ctx *h) {
             h->bwd_epoch = 0;
         }
         h->bwd_epoch++;
-        if (h->bf16) {
+        if (h->bf16 && h->bwd_scatter16) {
+            RUN(K_BWD_PERSIST, bwd_scatter_bf16(h->Ubwd6b, h->DG, h->DHy, h->G, h->C, h->DGx, cb, h->abortp, h->bwd_epoch,
+                                                h->ring_base_b, N, S, B, h->n_cus, h->st));
+            h->ring_base_b = bwd_scatter_bf16_ring_advance(h->ring_base_b, S);
+        } else if (h->bf16) {
             RUN(K_BWD_PERSIST, bwd_persistent(reinterpret_cast<const float4 *>(h->Ubwd16), h->DG, h->DHy, h->G, h->C, h->H,
                                               h->xi, fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp,
                                               h->bwd_epoch, N, S, B, h->bwd_cols, h->st, nullptr, h->DGb));
@@ -673,6 +681,14 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
         ALLOC(h->dYt_b, (size_t)256 * h->Tpad);
         ALLOC(h->DGt_b, G4 * (size_t)h->Tpad);
         ALLOC(h->dYb, (size_t)h->T * 256);
+        const char *bh = getenv("LSTM_HIP_BWD_HALVES"); // "0": the one-recurrence form (A/B; per handle)
+        h->bwd_scatter16 = !(bh && atoi(bh) == 0) && bwd_scatter_bf16_supported((int)N, (int)B, prop.multiProcessorCount);
+        if (h->bwd_scatter16) {
+            HIP_TRY(hipMalloc(&h->Ubwd6b, (size_t)8 * N * N));
+            h->DGx_floats = bwd_scatter_bf16_ring_floats((int)N, (int)B);
+            ALLOC(h->DGx, h->DGx_floats);
+            HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * h->DGx_floats));
+        }
     }
     if (h->persistent && bwd_uses_m4((int)N, h->bwd_cols, h->bf16)) {
         ALLOC(h->Ubwd4, N * N);
@@ -683,8 +699,9 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
         const int bhv = bh ? atoi(bh) : 1;
         h->bwd_halves = bhv == 0 ? 0 : (bhv | 1) * (int)bwd_scatter_supported((int)N, (int)B, prop.multiProcessorCount, want_fused);
         if (h->bwd_halves) { // hand-off through a sentinel ring
-            ALLOC(h->DGx, bwd_ring_floats((int)N, (int)B));
-            HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * bwd_ring_floats((int)N, (int)B)));
+            h->DGx_floats = bwd_ring_floats((int)N, (int)B);
+            ALLOC(h->DGx, h->DGx_floats);
+            HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * h->DGx_floats));
         }
     }
     if (h->persistent && !h->bf16 && fwd_uses_8col_form((int)N, (int)B, prop.multiProcessorCount)) {
@@ -718,7 +735,7 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     if (h->st2) (void)hipStreamSynchronize(h->st2);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->Ubwd4, h->Ufwd4, h->Hx, h->DGx, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
-                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->WhyT_b, h->Why_b, h->Ht_b, h->dYt_b, h->DGt_b, h->dYb, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
+                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->Ubwd6b, h->WhyT_b, h->Why_b, h->Ht_b, h->dYt_b, h->DGt_b, h->dYb, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->h_losses) (void)hipHostFree(h->h_losses);

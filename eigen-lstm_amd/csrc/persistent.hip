@@ -962,6 +962,32 @@ __device__ __forceinline__ u32x4 pack_bf16x8(const float4 &a, const float4 &b) {
     return v;
 }
 
+// Ubwd6b[kb][w][s][ab][l] = bf16 x 4 { U[gate*N + UW*kb + unit][output], k = gate*UW + unit = 4*ab + e, e = 0..3 }, output =
+// (w*NS + s)*64 + l, ab = 0 .. UW-1: the scatter form's image (k_bwd_scatter_bf16), 8 bytes per lane and (s, ab)
+__global__ __launch_bounds__(256) void k_pack_U6_bf16(const float *__restrict__ U, uint2 *__restrict__ Ubwd6b, int N, int UW) {
+    const int G4 = 4 * N, NS = N >= 512 ? N / 512 : 1, NPW = N / (64 * NS);
+    const size_t total = (size_t)N * N; // 8-byte elements: 4N*N values / 4
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(e & 63), ab = (int)((e >> 6) % UW);
+        const size_t r = (e >> 6) / UW;
+        const int sx = (int)(r % NS), w = (int)((r / NS) % NPW), kb = (int)(r / ((size_t)NS * NPW));
+        const int out = (w * NS + sx) * 64 + l;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int kk = 4 * ab + q, row = (kk / UW) * N + UW * kb + (kk % UW);
+            v[q] = U[(size_t)out * G4 + row];
+        }
+        Ubwd6b[e] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+}
+int bwd_scatter_bf16_units(int N);
+void pack_U6_bf16(const float *U, void *Ubwd6b, int N, hipStream_t st) {
+    const size_t n = (size_t)N * N;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_pack_U6_bf16, dim3(blocks), dim3(256), 0, st, U, reinterpret_cast<uint2 *>(Ubwd6b), N, bwd_scatter_bf16_units(N));
+}
 __global__ __launch_bounds__(256) void k_pack_U_bf16(const float *__restrict__ U, u32x4 *__restrict__ Ufwd16,
                                                      u32x4 *__restrict__ Ubwd16, int N) {
     const int G4 = 4 * N;
@@ -1908,6 +1934,292 @@ template <int N_, bool FUSE, bool STAMP = false> __global__ __launch_bounds__(BW
 #undef HSTAMP
 
 // ------------------------------------------------------------------------------------------------
+// backward recurrence, scatter form, bf16 operands (LSTM_HIP_BF16_RECURRENCE; N = 256 / 512 / 1024, 8-column groups): the
+// decomposition and ring of k_bwd_scatter with the recurrent product on v_mfma_f32_4x4x4_16b_bf16 -- dg_t rounded to
+// bfloat16 (RNE) on its way into LDS, U as a bf16 image (k_pack_U_bf16, Ubwd6b), fp32 accumulation, fp32 partial sums on the
+// ring -- which is what the oracle's bf16 recurrence mode computes (oracle/lstm_ref.c, ref_set_bf16_recurrence).  Half the
+// weight registers of the fp32 form, so hidden 1024 fits: a workgroup keeps its 64 gate rows for all N outputs in
+// N/16 registers per lane.  The bf16 path fuses nothing into the recurrence (DHy, dW, db, dWhy are separate launches),
+// so the roles are: waves 0-7 product (wave w: outputs [OW*w, OW*(w+1)), OW = max(64, N/8), in sets of 64), waves 8 / 9
+// elementwise of half A / B.  One instruction = 4 values of k for 64 outputs and 4 columns:
+//   D[column i][output j of the block] += sum_e dg[k = 4ab + e][column i] * U[k][output]      CBSZ = 4 / ABID = ab
+// ------------------------------------------------------------------------------------------------
+typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+struct BwdsbArgs {
+    const uint2 *Ubwd6b;
+    float *DG;
+    const float *DHy, *G, *C;
+    float *Qx;
+    unsigned *cnt, *abortp;
+    unsigned epoch;
+    int ring_base, S, B, NG, pinned, cfg;
+};
+// UW = units per workgroup: 16, or 32 where a group of N/16 workgroups would not fit one XCD (hidden 1024: 32 workgroups of
+// 128 gate rows each, a quarter of the chip per 8 columns, but every hand-off stays inside one L2 -- measured at hidden 512,
+// 64 streams: 182 us with XCD-local groups, 292 us with the same groups spread over the XCDs)
+template <int N_, int UW> struct BwdsbShape {
+    static constexpr int N = N_, NB = N / UW, KK = 4 * UW, NAB = KK / 4, NR = NAB / 16;
+    static constexpr int NS = N >= 512 ? N / 512 : 1, NPW = N / (64 * NS);
+    static constexpr int NEH = UW / 16, THREADS = (8 + 2 * NEH) * 64;
+};
+__host__ __device__ inline size_t bwdsb_ring_floats(int N, int UW, int B) {
+    const size_t nb = (size_t)N / UW;
+    return (size_t)HX_RING * ((B + 7) / 8) * 2 * nb * nb * (4 * UW);
+}
+// Hand-off without a reset store (BWDSB_TAGGED): a published partial sum carries the parity of its slot's use count in its last
+// mantissa bit (a perturbation of at most one fp32 ulp of a partial sum whose operands were rounded to bf16), so a consumer
+// tells this use of the slot from the previous one by that bit, in all four words of a 16-byte piece, and nobody has to write
+// the sentinel back: half the ring's write traffic.  The ring starts as all ones (parity 1), the first use publishes parity 0.
+#ifndef BWDSB_TAGGED
+#define BWDSB_TAGGED 1
+#endif
+__device__ __forceinline__ float bwdsb_mark(float v, unsigned phase) {
+    if (!BWDSB_TAGGED) return hx_canon(v);
+    return __uint_as_float((__float_as_uint(v) & ~1u) | phase);
+}
+__device__ __forceinline__ bool bwdsb_ready(const float4 &v, unsigned phase) {
+    if (!BWDSB_TAGGED) return hx_ready(v);
+    return ((__float_as_uint(v.x) & __float_as_uint(v.y) & __float_as_uint(v.z) & __float_as_uint(v.w) & 1u) == phase) &&
+           (((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) & 1u) == phase);
+}
+template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_bf16(const BwdsbArgs p) {
+    using Sh = BwdsbShape<N_, UW>;
+    constexpr int N = N_, G4 = 4 * N, NB = Sh::NB, NLD = NB / 4, KK = Sh::KK, NR = Sh::NR, NS = Sh::NS, NPW = Sh::NPW, NEH = Sh::NEH;
+    static_assert((N == 256 || N == 512 || N == 1024) && (UW == 16 || UW == 32) && NB % 4 == 0, "bf16 scatter form: shapes");
+    __shared__ __attribute__((aligned(16))) unsigned short dgl[2][2][4 * KK]; // [half][step parity][column][k]: bf16 dg_t
+    __shared__ unsigned s_done[2][2], s_loc[2];
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int NG = p.NG;
+    int kb, g;
+    if (p.pinned) { // 8 * NB workgroups launched: workgroup i runs on XCD i % 8; group g lives on XCD g, the rest leave
+        g = (int)blockIdx.x & 7, kb = (int)blockIdx.x >> 3;
+        if (g >= NG) return;
+    } else {
+        kb = (int)blockIdx.x / NG, g = (int)blockIdx.x % NG;
+    }
+    const int S = p.S, B = p.B, ring_base = p.ring_base;
+    float *Qx = p.Qx;
+    const __amdgpu_buffer_rsrc_t rQ = make_rsrc(Qx, bwdsb_ring_floats(N, UW, B) * sizeof(float));
+    unsigned *xcc_tab = p.cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
+    if (tid == 0) {
+        s_abort = 0;
+        s_done[0][0] = s_done[0][1] = s_done[1][0] = s_done[1][1] = 0;
+        s_loc[0] = s_loc[1] = 0;
+        if (XCD_LOCAL) {
+            __hip_atomic_store(xcc_tab + kb, (p.epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // visible before anything this workgroup publishes
+        }
+    }
+    __syncthreads();
+    auto give_up = [&]() {
+        if (l == 0) {
+            __hip_atomic_store(p.abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto lds_wait = [&](unsigned *word, unsigned want) -> bool {
+        for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+            if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) {
+                asm volatile("" ::: "memory");
+                return true;
+            }
+            if (__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return false;
+    };
+    if (w < 8) {
+        // ---------------- product waves ----------------
+        __builtin_amdgcn_s_setprio(2);
+        const bool active = w < NPW;
+        const int lb = l >> 2, lj = l & 3;
+        uint2 a[NS][NR][16]; // bf16 x 4: U[row(k = 4(16r + ab) + e)][output] for e = 0..3
+#pragma unroll
+        for (int sx = 0; sx < NS; sx++)
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+#pragma unroll
+                for (int ab = 0; ab < 16; ab++)
+                    a[sx][r][ab] = active ? p.Ubwd6b[(((((size_t)kb * NPW + w) * NS + sx) * NR + r) * 16 + ab) * 64 + l] : uint2{0u, 0u};
+#pragma unroll
+        for (int sx = 0; sx < NS; sx++)
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+#pragma unroll
+                for (int ab = 0; ab < 16; ab++) asm volatile("" ::"v"(a[sx][r][ab].x), "v"(a[sx][r][ab].y)); // complete before the loop
+        for (int t = S - 1; t >= 2; t--) {
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                if (!lds_wait(&s_done[hf][t & 1], (unsigned)(NEH * ((S - 1 - t) / 2 + 1)))) {
+                    give_up();
+                    return;
+                }
+                if (!active) continue;
+                bf16x4_t av[NR]; // column lj, k = 4*(16r + lb) .. +3
+#pragma unroll
+                for (int r = 0; r < NR; r++)
+                    av[r] = __builtin_bit_cast(bf16x4_t, *reinterpret_cast<const uint2 *>(&dgl[hf][t & 1][lj * KK + 4 * (16 * r + lb)]));
+                const bool local = t < S - 1 && __hip_atomic_load(&s_loc[hf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's older stores (the last reset) are complete
+                const int seq = ring_base + (S - 1 - t); // publication number: slot = seq & 3, phase = bit 2
+                const int spub = seq & (HX_RING - 1), srst = (seq + 2) & (HX_RING - 1);
+                const unsigned phase = (unsigned)(seq >> 2) & 1u;
+#pragma unroll
+                for (int sx = 0; sx < NS; sx++) {
+                    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+#define SB4(r, ab)                                                                                                           \
+    c0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[r], __builtin_bit_cast(bf16x4_t, a[sx][r][ab + 0]), c0, 4, ab + 0, 0);    \
+    c1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[r], __builtin_bit_cast(bf16x4_t, a[sx][r][ab + 1]), c1, 4, ab + 1, 0);    \
+    c2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[r], __builtin_bit_cast(bf16x4_t, a[sx][r][ab + 2]), c2, 4, ab + 2, 0);    \
+    c3 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[r], __builtin_bit_cast(bf16x4_t, a[sx][r][ab + 3]), c3, 4, ab + 3, 0);
+                    if (!(p.cfg & 1)) {
+#pragma unroll
+                        for (int r = 0; r < NR; r++) { SB4(r, 0) SB4(r, 4) SB4(r, 8) SB4(r, 12) }
+                    }
+#undef SB4
+                    float4 q;
+                    q.x = bwdsb_mark((c0[0] + c1[0]) + (c2[0] + c3[0]), phase);
+                    q.y = bwdsb_mark((c0[1] + c1[1]) + (c2[1] + c3[1]), phase);
+                    q.z = bwdsb_mark((c0[2] + c1[2]) + (c2[2] + c3[2]), phase);
+                    q.w = bwdsb_mark((c0[3] + c1[3]) + (c2[3] + c3[3]), phase);
+                    const float sv = __uint_as_float(HX_SENT);
+                    const float4 sent = {sv, sv, sv, sv};
+                    const int out = (w * NS + sx) * 64 + l, d = out / UW, u = out % UW;
+                    const int e_pub = ((((spub * NG + g) * 2 + hf) * NB + d) * NB + kb) * KK + u * 4;
+                    const int e_rst = ((((srst * NG + g) * 2 + hf) * NB + d) * NB + kb) * KK + u * 4;
+                    if (XCD_LOCAL && local) {
+                        *reinterpret_cast<float4 *>(Qx + e_pub) = q;
+                        if (!BWDSB_TAGGED) *reinterpret_cast<float4 *>(Qx + e_rst) = sent;
+                    } else {
+                        st_sc1(q, rQ, e_pub * (int)sizeof(float));
+                        if (!BWDSB_TAGGED) st_sc1(sent, rQ, e_rst * (int)sizeof(float));
+                    }
+                }
+            }
+        }
+    } else {
+        // ---------------- elementwise waves: NEH per half (16 units each); lane = column*16 + unit ----------------
+        const int hf = (w - 8) / NEH, uh = (w - 8) % NEH;
+        __builtin_amdgcn_s_setprio(3);
+        const int cc = l >> 4, jj = l & 15;
+        const int ecol = 8 * g + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
+        const int uu = 16 * uh + jj, j = UW * kb + uu;
+        float dcn = 0.0f; // dcnext, R/lstm.cc:217
+        bool local_pub = false;
+        float ig, og, fg, ug, cv, cp, dhy;
+        auto fetch = [&](int tu) {
+            const float *gc = p.G + ((size_t)tu * B + ecolc) * G4 + j;
+            ig = gc[0], og = gc[N], fg = gc[2 * N], ug = gc[3 * N];
+            cv = p.C[((size_t)tu * B + ecolc) * N + j], cp = p.C[((size_t)(tu - 1) * B + ecolc) * N + j];
+            dhy = p.DHy[((size_t)tu * B + ecolc) * N + j]; // Why^T dy_tu, a launch of its own in the bf16 path
+        };
+        fetch(S - 1);
+        for (int t = S - 1; t >= 1; t--) {
+            float dhn = 0.0f;
+            if (t < S - 1) {
+                // Q_{t+1}: this lane's piece = sources 4i + (l >> 4), unit 16*uh + (l & 15), the four columns
+                const int seq = ring_base + (S - 2 - t); // publication number of Q_{t+1}
+                const size_t slot = (size_t)(seq & (HX_RING - 1));
+                const unsigned phase = (unsigned)(seq >> 2) & 1u;
+                const int off = (int)((((((slot * NG + g) * 2 + hf) * NB + kb) * NB + (size_t)(l >> 4)) * KK + (size_t)(16 * uh + (l & 15)) * 4) * sizeof(float));
+                float4 v[NLD];
+                bool ok = false;
+                for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                    bool gd = true;
+#pragma unroll
+                    for (int i = 0; i < NLD; i++) v[i] = ld_sc1(rQ, off + i * (4 * KK * (int)sizeof(float)));
+#pragma unroll
+                    for (int i = 0; i < NLD; i++) gd = gd && bwdsb_ready(v[i], phase);
+                    if (__all(gd)) {
+                        ok = true;
+                        break;
+                    }
+                    if ((spins & 255) == 255 && __hip_atomic_load(p.abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                }
+                if (!ok) {
+                    give_up();
+                    return;
+                }
+                float4 sm = v[0];
+#pragma unroll
+                for (int i = 1; i < NLD; i++) {
+                    sm.x += v[i].x;
+                    sm.y += v[i].y;
+                    sm.z += v[i].z;
+                    sm.w += v[i].w;
+                }
+                const int q = l >> 4;
+                const float k0 = (q & 1) ? sm.y : sm.x, k1 = (q & 1) ? sm.w : sm.z;
+                const float s0 = (q & 1) ? sm.x : sm.y, s1 = (q & 1) ? sm.z : sm.w;
+                const float z0 = k0 + xchg_row16(s0, l), z1 = k1 + xchg_row16(s1, l);
+                const float keep = (q & 2) ? z1 : z0, send = (q & 2) ? z0 : z1;
+                dhn = keep + xchg_half32(send, l);
+            }
+            if (XCD_LOCAL && t == S - 2) { // every workgroup of the group has published Q_{S-1}, its XCC id before it
+                unsigned mine = 0;
+                bool same = true;
+                if (l < NB) {
+                    mine = __hip_atomic_load(xcc_tab + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    same = (mine >> 4) == p.epoch;
+                }
+                const unsigned first = __builtin_amdgcn_readfirstlane(mine);
+                if (l < NB) same = same && mine == first;
+                local_pub = XCD_FORCE_LOCAL || __all(same);
+                if (l == 0 && uh == 0)
+                    __hip_atomic_store(&s_loc[hf], local_pub ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            const float dh = dhy + dhn;                         // R/lstm.cc:228
+            float dcv = dh * og + dcn;                          // :233
+            dcv = dcv * (1.0f - cv * cv);                       // :235
+            const float d_o = (dh * cv) * (og * (1.0f - og));   // :238,244
+            const float d_i = (dcv * ug) * (ig * (1.0f - ig));  // :239,244
+            const float d_f = (dcv * cp) * (fg * (1.0f - fg));  // :240,244
+            const float d_u = (dcv * ig) * (1.0f - ug * ug);    // :241,247
+            dcn = dcv * fg;                                     // :256
+            {   // dg_t, rounded to bfloat16, for this workgroup's product waves: [column][k = gate*UW + unit]
+                unsigned short *dp = &dgl[hf][t & 1][cc * KK + uu];
+                dp[0] = __builtin_bit_cast(unsigned short, (__bf16)d_i);
+                dp[UW] = __builtin_bit_cast(unsigned short, (__bf16)d_o);
+                dp[2 * UW] = __builtin_bit_cast(unsigned short, (__bf16)d_f);
+                dp[3 * UW] = __builtin_bit_cast(unsigned short, (__bf16)d_u);
+                asm volatile("" ::: "memory");
+                if (l == 0) __hip_atomic_fetch_add(&s_done[hf][t & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // off the chain: the plain fp32 DG the dU / dW / db launches read afterwards (4x4 DPP transpose, one 16-byte store)
+            const int ta = jj & 3, tq = jj >> 2;
+            float t0 = d_i, t1 = d_o, t2 = d_f, t3 = d_u;
+            {
+                const float lo = (ta & 1) ? t0 : t1, hi = (ta & 1) ? t2 : t3;
+                const float rlo = dpp_f<0xB1>(lo), rhi = dpp_f<0xB1>(hi); // quad_perm [1,0,3,2]
+                if (ta & 1) {
+                    t0 = rlo;
+                    t2 = rhi;
+                } else {
+                    t1 = rlo;
+                    t3 = rhi;
+                }
+                const float s0 = (ta & 2) ? t0 : t2, s1 = (ta & 2) ? t1 : t3;
+                const float r0 = dpp_f<0x4E>(s0), r1 = dpp_f<0x4E>(s1); // quad_perm [2,3,0,1]
+                if (ta & 2) {
+                    t0 = r0;
+                    t1 = r1;
+                } else {
+                    t2 = r0;
+                    t3 = r1;
+                }
+            }
+            if (ecol < B && !(p.cfg & 4)) {
+                const float4 v = {t0, t1, t2, t3};
+                *reinterpret_cast<float4 *>(p.DG + ((size_t)t * B + ecol) * G4 + ta * N + UW * kb + 16 * uh + 4 * tq) = v;
+            }
+            if (t >= 2 && !(p.cfg & 8)) fetch(t - 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward recurrence, t = S-1..1, N = 32*NR4W.  grid (N/16, ceil(B/COLS)), 512 threads.
 // Workgroup (kb, g) owns hidden units 16kb..16kb+15 for column group g (COLS = 8 or 16 batch columns): the tile
 // dhnext = U^T * dg[t+1] (R/lstm.cc:255) with K = 4N split over its 8 waves (U^T fragments in VGPRs) -- 16x16x4 MFMA
@@ -2690,6 +3002,40 @@ void bwd_scatter(const float4 *Ubwd6, float *DG, const float *Why, const float *
     else
         BS_GO(512, false, false);
 #undef BS_GO
+}
+
+// bf16 scatter form (k_bwd_scatter_bf16): N = 256 / 512 / 1024, 8-column groups.  Hidden 1024 runs 32 units to a workgroup so
+// that a group (32 workgroups) fits one XCD; with fewer than 8 groups the launch is pinned: 8 * NB workgroups, group g = the
+// ones the dispatcher's round robin puts on XCD g (workgroup i -> XCD i % 8), the others leave at once.  (The kernel checks
+// the placement it really got, HW_REG_XCC_ID, and keeps to device-scope stores where it is not what was asked for.)
+int bwd_scatter_bf16_units(int N) { return N == 1024 ? 32 : 16; }
+// publication number of the next launch's first hand-off (slot = low two bits, parity = bit 2)
+int bwd_scatter_bf16_ring_advance(int base, int S) { return (base + (S > 2 ? S - 2 : 0)) & 7; }
+static bool bwdsb_pinned(int N, int B, int n_cus) {
+    const int NB = N / bwd_scatter_bf16_units(N), NG = (B + 7) / 8;
+    return NG < 8 && 8 * NB <= n_cus;
+}
+size_t bwd_scatter_bf16_ring_floats(int N, int B) { return bwdsb_ring_floats(N, bwd_scatter_bf16_units(N), B); }
+bool bwd_scatter_bf16_supported(int N, int B, int n_cus) {
+    if (N != 256 && N != 512 && N != 1024) return false;
+    const size_t grid = (size_t)(N / bwd_scatter_bf16_units(N)) * ((B + 7) / 8);
+    int per_cu = 0;
+    if (N == 1024) per_cu = blocks_per_cu(k_bwd_scatter_bf16<1024, 32>, BwdsbShape<1024, 32>::THREADS);
+    else if (N == 512) per_cu = blocks_per_cu(k_bwd_scatter_bf16<512, 16>, BwdsbShape<512, 16>::THREADS);
+    else per_cu = blocks_per_cu(k_bwd_scatter_bf16<256, 16>, BwdsbShape<256, 16>::THREADS);
+    return per_cu >= 1 && grid <= (size_t)n_cus;
+}
+void bwd_scatter_bf16(const void *Ubwd6b, float *DG, const float *DHy, const float *G, const float *C, float *Qx, unsigned *cnt,
+                      unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int n_cus, hipStream_t st) {
+    const int NB = N / bwd_scatter_bf16_units(N), NG = (B + 7) / 8;
+    static const int spread = getenv("LSTM_HIP_BWD_SPREAD") && atoi(getenv("LSTM_HIP_BWD_SPREAD")) ? 1 : 0;
+    const int pinned = bwdsb_pinned(N, B, n_cus) && !spread;
+    static const int cfg = getenv("LSTM_HIP_BWDSB_CFG") ? atoi(getenv("LSTM_HIP_BWDSB_CFG")) : 0; // timing experiments only
+    const dim3 grid(pinned ? 8 * NB : NB * NG);
+    const BwdsbArgs args = {reinterpret_cast<const uint2 *>(Ubwd6b), DG, DHy, G, C, Qx, cnt, abortp, epoch, ring_base, S, B, NG, pinned, cfg};
+    if (N == 1024) hipLaunchKernelGGL((k_bwd_scatter_bf16<1024, 32>), grid, dim3(BwdsbShape<1024, 32>::THREADS), 0, st, args);
+    else if (N == 512) hipLaunchKernelGGL((k_bwd_scatter_bf16<512, 16>), grid, dim3(BwdsbShape<512, 16>::THREADS), 0, st, args);
+    else hipLaunchKernelGGL((k_bwd_scatter_bf16<256, 16>), grid, dim3(BwdsbShape<256, 16>::THREADS), 0, st, args);
 }
 
 void bwd_persistent(const float4 *Ubwd, float *DG, const float *DHy, const float *G, const float *C, const float *H,
