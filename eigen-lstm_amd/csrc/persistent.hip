@@ -732,9 +732,14 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
     // workgroup's h of the step in between), and its early count would stand in for the late wave's missing one.
     __shared__ unsigned s_done[2][2];
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int NB3 = gridDim.x, NG = gridDim.y;
+    // poll_cfg bits 16-19: pinned launch (fewer than 8 groups): gridDim.y = 8, workgroup i runs on XCD i % 8, group g is the
+    // workgroups of XCD g, the workgroups of the other XCDs leave at once
+    const int pin_ng = (poll_cfg >> 16) & 15;
+    const int NB3 = gridDim.x, NG = pin_ng ? pin_ng : (int)gridDim.y;
     const int lin_ = blockIdx.x + NB3 * blockIdx.y;
-    const int kb = GROUP_REMAP ? lin_ / NG : (int)blockIdx.x, g = GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
+    const int kb = pin_ng ? lin_ >> 3 : GROUP_REMAP ? lin_ / NG : (int)blockIdx.x;
+    const int g = pin_ng ? lin_ & 7 : GROUP_REMAP ? lin_ % NG : (int)blockIdx.y;
+    if (pin_ng && g >= NG) return;
     const __amdgpu_buffer_rsrc_t rH = make_rsrc(H, (size_t)S * N * B * sizeof(float));
     const __amdgpu_buffer_rsrc_t rHx = make_rsrc(Hx, (size_t)HX_RING * N * B * sizeof(float));
     unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
@@ -1328,12 +1333,16 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -
     const int ring_base = p.ring_base, S = p.S, B = p.B, cfg = p.cfg;                                                           \
     unsigned long long *stamps = p.stamps;                                                                                      \
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;                                                                    \
-    const int NBK = gridDim.x, NG = gridDim.y;                                                                                  \
+    /* cfg bits 16-19: pinned launch (fewer than 8 groups): gridDim.y = 8, workgroup i runs on XCD i % 8 and group g is the   */ \
+    /* workgroups of XCD g; those of the other XCDs leave at once (k_bwd_scatter)                                             */ \
+    const int pin_ng_ = (cfg >> 16) & 15;                                                                                       \
+    const int NBK = gridDim.x, NG = pin_ng_ ? pin_ng_ : (int)gridDim.y;                                                         \
     const int lin_ = blockIdx.x + NBK * blockIdx.y;                                                                             \
     /* cfg bit 16 (tests): keep the dispatch-order mapping, which spreads every column group over all XCDs -- the placement  */ \
     /* the XCD-local publish must detect and decline                                                                         */ \
     const bool remap_ = GROUP_REMAP && !(cfg & 16);                                                                             \
-    const int kb = remap_ ? lin_ / NG : (int)blockIdx.x, g = remap_ ? lin_ % NG : (int)blockIdx.y;                              \
+    const int kb = pin_ng_ ? lin_ >> 3 : remap_ ? lin_ / NG : (int)blockIdx.x;                                                  \
+    const int g = pin_ng_ ? lin_ & 7 : remap_ ? lin_ % NG : (int)blockIdx.y;                                                    \
     const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DGx, (size_t)HX_RING * G4 * B * sizeof(float));                                \
     unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;                                                               \
     /* a wave that gives up: the abort word ends the launch everywhere, the LDS word releases this workgroup's other waves */   \
@@ -1909,6 +1918,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_el
 }
 template <int N_, bool FUSE, bool STAMP = false> __global__ __launch_bounds__(BWDH_THREADS) void k_bwd_scatter(const BwdhArgs p) {
     BWDH_COMMON(p)
+    if (pin_ng_ && g >= NG) return; // pinned launch: this workgroup sits on an XCD that hosts no group
     if (tid == 0) {
         *s_abort = 0;
         s_done[0] = s_done[1] = s_done[2] = s_done[3] = 0;
@@ -2126,6 +2136,17 @@ template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THRE
                 const int off = (int)((((((slot * NG + g) * 2 + hf) * NB + kb) * NB + (size_t)(l >> 4)) * KK + (size_t)(16 * uh + (l & 15)) * 4) * sizeof(float));
                 float4 v[NLD];
                 bool ok = false;
+                if (p.cfg & 16) { // hint: one 16-byte piece of one source, one lane, until it flips
+                    const int hsrc = (kb + 1) % NB;
+                    const int hoff = (int)((((((slot * NG + g) * 2 + hf) * NB + kb) * NB + (size_t)hsrc) * KK + (size_t)(16 * uh) * 4) * sizeof(float));
+                    const float pv = __uint_as_float(phase);
+                    for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                        float4 hv = {pv, pv, pv, pv};
+                        if (l == 0) hv = ld_sc1(rQ, hoff);
+                        if (__all(bwdsb_ready(hv, phase))) break;
+                        if ((spins & 255) == 255 && __hip_atomic_load(p.abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    }
+                }
                 for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
                     bool gd = true;
 #pragma unroll
@@ -2137,6 +2158,7 @@ template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THRE
                         break;
                     }
                     if ((spins & 255) == 255 && __hip_atomic_load(p.abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    for (int i = 0; i < ((p.cfg >> 5) & 7); i++) __builtin_amdgcn_s_sleep(1);
                 }
                 if (!ok) {
                     give_up();
@@ -2890,7 +2912,11 @@ bool fwd_uses_two_half_form(int N, int B, int n_cus) { return (N == 512 || N == 
 void fwd_persistent6(const float4 *Ufwd5, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
                      int poll_cfg, hipStream_t st, unsigned long long *stamps) {
-    const dim3 grid(N / 16, (B + 7) / 8), block(FWD4_THREADS);
+    const int NGh = (B + 7) / 8;
+    static const bool no_pin = getenv("LSTM_HIP_NO_PIN") && atoi(getenv("LSTM_HIP_NO_PIN")); // A/B
+    const bool pinned = NGh < 8 && !no_pin; // one group per XCD (see the kernel)
+    poll_cfg = (poll_cfg & 0xffff) | (pinned ? NGh << 16 : 0);
+    const dim3 grid(N / 16, pinned ? 8 : NGh), block(FWD4_THREADS);
 #define F6_GO(...)                                                                                                            \
     hipLaunchKernelGGL((k_fwd_persistent6<__VA_ARGS__>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch, \
                        ring_base, S, B, poll_cfg, stamps)
@@ -2980,7 +3006,12 @@ bool bwd_scatter_supported(int N, int B, int n_cus, bool fused) {
 void bwd_scatter(const float4 *Ubwd6, float *DG, const float *Why, const float *dY, const float *G, const float *C, const float *H,
                  const int32_t *xi, float *gpart, float *Qx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N,
                  int S, int B, int cfg, hipStream_t st, unsigned long long *stamps) {
-    const dim3 grid(N / 16, (B + 7) / 8), block(BWDH_THREADS);
+    // fewer than 8 groups: pinned launch, one group per XCD (see BWDH_COMMON); cfg bit 16 (spread mapping, tests) keeps the plain one
+    const int NGh = (B + 7) / 8;
+    static const bool no_pin = getenv("LSTM_HIP_NO_PIN") && atoi(getenv("LSTM_HIP_NO_PIN")); // A/B
+    const bool pinned = NGh < 8 && !(cfg & 16) && !no_pin;
+    if (pinned) cfg |= NGh << 16;
+    const dim3 grid(N / 16, pinned ? 8 : NGh), block(BWDH_THREADS);
     const bool fuse = gpart != nullptr;
     const size_t lds = bwdh_lds_bytes(fuse);
 #define BS_GO(...)                                                                                                                   \
