@@ -95,10 +95,19 @@ void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, 
 // N*N*8 bytes), partial-sum ring Qx as in bwd_scatter; reads DHy (a launch of its own in the bf16 path), writes the fp32 DG
 bool bwd_scatter_bf16_supported(int N, int B, int n_cus);
 void pack_U6_bf16(const float *U, void *Ubwd6b, int N, hipStream_t st);
+// two-half form of the bf16 forward recurrence (k_fwd_halves_bf16): weights image Ufwd6b (N*N*8 bytes), bf16 sentinel ring Hxb
+// (fwd_halves_bf16_ring_halfwords, all ones at rest; slots advance with fwd_ring_advance)
+bool fwd_halves_bf16_supported(int N, int B, int n_cus);
+void pack_Ufwd6_bf16(const float *U, void *img, int N, hipStream_t st);
+size_t fwd_halves_bf16_ring_halfwords(int N, int B);
+void fwd_halves_bf16(const void *Ufwd6b, const float *W, const float *bias, float *H, unsigned short *Hb, float *C, float *G,
+                     const int32_t *xi, void *Hxb, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S,
+                     int B, bool fast, int n_cus, hipStream_t st, unsigned long long *stamps);
 size_t bwd_scatter_bf16_ring_floats(int N, int B);
 int bwd_scatter_bf16_ring_advance(int base, int S);
 void bwd_scatter_bf16(const void *Ubwd6b, float *DG, const float *DHy, const float *G, const float *C, float *Qx, unsigned *cnt,
-                      unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int n_cus, hipStream_t st);
+                      unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int n_cus, hipStream_t st,
+                      unsigned long long *stamps);
 size_t bwd_partial_floats(int N);
 int bwd_group_cols(int N, int B, int n_cus); // 8 or 16 batch columns per backward workgroup
 

@@ -105,6 +105,8 @@ struct lstm_hip_ctx {
     void *Ufwd16 = nullptr, *Ubwd16 = nullptr;    // bf16 fragment images of U
     void *Ubwd6b = nullptr;                       // ... and the scatter-form backward's (bwd_scatter16)
     bool bwd_scatter16 = false;                   // bf16 backward recurrence in its scatter form (k_bwd_scatter_bf16)
+    void *Ufwd6b = nullptr, *Hxb = nullptr;       // two-half bf16 forward form: weights image, bf16 hand-off ring
+    bool fwd_halves16 = false;
     // bf16 operands of the four time-batched products, k contiguous (kernels.h, gemm_bf16): Why^T and Why; per window
     // h^T [N][SBpad], dy^T [256][Tpad], dg^T [4N][Tpad] and dy [T][256]
     unsigned short *WhyT_b = nullptr, *Why_b = nullptr, *Ht_b = nullptr, *dYt_b = nullptr, *DGt_b = nullptr, *dYb = nullptr;
@@ -234,6 +236,10 @@ int check_abort(lstm_hip_ctx *h) {
             HIP_TRY(hipMemsetAsync(h->Hx, 0xff, sizeof(float) * fwd_ring_floats(h->cfg.N, h->cfg.B), h->st));
             h->ring_base = 0;
         }
+        if (h->Hxb) {
+            HIP_TRY(hipMemsetAsync(h->Hxb, 0xff, sizeof(unsigned short) * fwd_halves_bf16_ring_halfwords(h->cfg.N, h->cfg.B), h->st));
+            h->ring_base = 0;
+        }
         if (h->DGx) {
             HIP_TRY(hipMemsetAsync(h->DGx, 0xff, sizeof(float) * h->DGx_floats, h->st));
             h->ring_base_b = 0;
@@ -264,8 +270,15 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
     if (h->bf16) {
         if (!h->packed16) {
             RUN(K_PACK_U, (pack_U_bf16(h->P + h->pl.U, h->Ufwd16, h->Ubwd16, N, h->st),
-                           h->bwd_scatter16 ? pack_U6_bf16(h->P + h->pl.U, h->Ubwd6b, N, h->st) : (void)0));
+                           h->bwd_scatter16 ? pack_U6_bf16(h->P + h->pl.U, h->Ubwd6b, N, h->st) : (void)0,
+                           h->fwd_halves16 ? pack_Ufwd6_bf16(h->P + h->pl.U, h->Ufwd6b, N, h->st) : (void)0));
             h->packed16 = true;
+        }
+        if (h->fwd_halves16) {
+            RUN(K_FWD_PERSIST, fwd_halves_bf16(h->Ufwd6b, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi, h->Hxb,
+                                               h->cnt, h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->n_cus, h->st, h->stamps));
+            h->ring_base = fwd_ring_advance(h->ring_base, S);
+            return 0;
         }
         RUN(K_FWD_PERSIST, fwd_persistent_bf16(h->Ufwd16, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi,
                                                h->cnt, h->abortp, h->fwd_epoch, N, S, B, fast, h->st, h->n_cus));
@@ -376,7 +389,7 @@ int do_backward(lstm_hip_ctx *h) {
         h->bwd_epoch++;
         if (h->bf16 && h->bwd_scatter16) {
             RUN(K_BWD_PERSIST, bwd_scatter_bf16(h->Ubwd6b, h->DG, h->DHy, h->G, h->C, h->DGx, cb, h->abortp, h->bwd_epoch,
-                                                h->ring_base_b, N, S, B, h->n_cus, h->st));
+                                                h->ring_base_b, N, S, B, h->n_cus, h->st, h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr));
             h->ring_base_b = bwd_scatter_bf16_ring_advance(h->ring_base_b, S);
         } else if (h->bf16) {
             RUN(K_BWD_PERSIST, bwd_persistent(reinterpret_cast<const float4 *>(h->Ubwd16), h->DG, h->DHy, h->G, h->C, h->H,
@@ -583,7 +596,9 @@ int lstm_hip_create(const lstm_hip_config *cfg, lstm_hip_t **out) {
             return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE needs the persistent engine and N a multiple of 128, <= 1024 (N=%d, B=%d)", cfg->N, cfg->B);
         if (cfg->B % 8 != 0)
             return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE needs a multiple of 8 streams (16-byte aligned bf16 operand rows); B=%d", cfg->B);
-        if (!persistent_supported_bf16(cfg->N, cfg->B, prop.multiProcessorCount, false))
+        // the two-half forms (one workgroup per CU, 8-column groups) or, where a shape has none, the one-recurrence forms
+        if (!(fwd_halves_bf16_supported(cfg->N, cfg->B, prop.multiProcessorCount) && bwd_scatter_bf16_supported(cfg->N, cfg->B, prop.multiProcessorCount)) &&
+            !persistent_supported_bf16(cfg->N, cfg->B, prop.multiProcessorCount, false))
             return fail(LSTM_HIP_EINVAL, "LSTM_HIP_BF16_RECURRENCE: the bf16 recurrence grids for N=%d, B=%d are not co-resident on %d CUs",
                         cfg->N, cfg->B, prop.multiProcessorCount);
     }
@@ -681,8 +696,17 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
         ALLOC(h->dYt_b, (size_t)256 * h->Tpad);
         ALLOC(h->DGt_b, G4 * (size_t)h->Tpad);
         ALLOC(h->dYb, (size_t)h->T * 256);
-        const char *bh = getenv("LSTM_HIP_BWD_HALVES"); // "0": the one-recurrence form (A/B; per handle)
-        h->bwd_scatter16 = !(bh && atoi(bh) == 0) && bwd_scatter_bf16_supported((int)N, (int)B, prop.multiProcessorCount);
+        // "0": the one-recurrence forms (A/B; per handle) -- where the shape has them
+        const bool older = persistent_supported_bf16(cfg->N, cfg->B, prop.multiProcessorCount, false);
+        const char *bh = getenv("LSTM_HIP_BWD_HALVES");
+        h->bwd_scatter16 = !(older && bh && atoi(bh) == 0) && bwd_scatter_bf16_supported((int)N, (int)B, prop.multiProcessorCount);
+        const char *fh = getenv("LSTM_HIP_FWD_HALVES");
+        h->fwd_halves16 = !(older && fh && atoi(fh) == 0) && fwd_halves_bf16_supported((int)N, (int)B, prop.multiProcessorCount);
+        if (h->fwd_halves16) {
+            HIP_TRY(hipMalloc(&h->Ufwd6b, (size_t)8 * N * N));
+            HIP_TRY(hipMalloc(&h->Hxb, sizeof(unsigned short) * fwd_halves_bf16_ring_halfwords((int)N, (int)B)));
+            HIP_TRY(hipMemset(h->Hxb, 0xff, sizeof(unsigned short) * fwd_halves_bf16_ring_halfwords((int)N, (int)B)));
+        }
         if (h->bwd_scatter16) {
             HIP_TRY(hipMalloc(&h->Ubwd6b, (size_t)8 * N * N));
             h->DGx_floats = bwd_scatter_bf16_ring_floats((int)N, (int)B);
@@ -720,7 +744,9 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
-    if (h->persistent && (cfg->flags & LSTM_HIP_DEBUG_STAMPS) && cfg->N == 512 && h->Hx && h->Ubwd4) ALLOC(h->stamps, 4 * S * 16);
+    if (h->persistent && (cfg->flags & LSTM_HIP_DEBUG_STAMPS) &&
+        ((cfg->N == 512 && h->Hx && h->Ubwd4) || (h->fwd_halves16 && h->bwd_scatter16)))
+        ALLOC(h->stamps, 4 * S * 16);
     HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
@@ -735,7 +761,7 @@ int lstm_hip_destroy(lstm_hip_t *h) {
     if (h->st2) (void)hipStreamSynchronize(h->st2);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     void *bufs[] = {h->P, h->dP, h->mem, h->Ufwd, h->Ubwd, h->Ubwd4, h->Ufwd4, h->Hx, h->DGx, h->H, h->C, h->G, h->DG, h->Y, h->Pr, h->DHy, h->dcnext,
-                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->Ubwd6b, h->WhyT_b, h->Why_b, h->Ht_b, h->dYt_b, h->DGt_b, h->dYb, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
+                    h->colloss, h->dby_part, h->slabs, h->slabs_dU, h->gpart, h->Hb, h->DGb, h->Ufwd16, h->Ubwd16, h->Ubwd6b, h->Ufwd6b, h->Hxb, h->WhyT_b, h->Why_b, h->Ht_b, h->dYt_b, h->DGt_b, h->dYb, h->dw_scratch, h->xi, h->ti, h->Xr, h->Tr, h->head, h->cnt, h->abortp, h->stamps, h->d_loss, h->d_losses, h->text, h->pos};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->h_losses) (void)hipHostFree(h->h_losses);
@@ -1166,7 +1192,7 @@ int lstm_hip_sample(lstm_hip_t *h, float *h0, float *c0, const double *u, int32_
 
 int lstm_hip_debug_stamps(lstm_hip_t *h, uint64_t *out, size_t count) {
     CHECK(h);
-    if (!h->stamps) return fail(LSTM_HIP_ESTATE, "handle was not created with LSTM_HIP_DEBUG_STAMPS at hidden 512 on the 8-column forms");
+    if (!h->stamps) return fail(LSTM_HIP_ESTATE, "handle was not created with LSTM_HIP_DEBUG_STAMPS on a shape whose two-half forms carry stamps (fp32: hidden 512; bf16: any)");
     const size_t have = (size_t)4 * h->cfg.S * 16;
     HIP_TRY(hipMemcpyAsync(out, h->stamps, sizeof(uint64_t) * (count < have ? count : have), hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));

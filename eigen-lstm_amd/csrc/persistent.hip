@@ -34,6 +34,7 @@
 //
 // Residency: all workgroups must be co-resident (they wait on each other); the host checks the grid
 // against the occupancy of the device and falls back to the per-step engine otherwise.
+#include <type_traits>
 #include "kernels.h"
 
 #include <cstdlib>
@@ -1270,6 +1271,305 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward recurrence, two half-groups per workgroup, bf16 operands (LSTM_HIP_BF16_RECURRENCE; N = 256 / 512 / 1024, 8-column
+// groups): k_fwd_persistent6 with the product on v_mfma_f32_4x4x4_16b_bf16.  UW units to a workgroup: 16, or 32 at hidden
+// 1024 so that a group is 32 workgroups and fits one XCD (pinned launch as in k_bwd_scatter_bf16): every hand-off of the
+// group then stays inside that XCD's L2.  h_t travels as bfloat16 (RNE, what the product consumes) through a 4-slot sentinel
+// ring Hxb[slot][column][N]: a lane's A operand is one 8-byte load (4 values of k of its column).
+//   D[column i][gate j of unit 16*set + u] += sum_e h[k = Kw*w + 64*r + 4*ab + e][column i] * U[gate j of unit][k]
+//   lane = 4*u + j on the weights' side, 4*ab + i on h's side; CBSZ = 4 / ABID = ab
+// Waves 0-7: the product (K split eight ways, half A then half B); waves 8..: gates / cell / publish, UW/16 waves per half.
+// (v_mfma_f32_4x4x4_16b_bf16 issues in 16 cycles -- stamps: 16 of them 232-264 cycles, 64 of them 1 450-1 800 with the
+// SIMD's other product wave beside -- twice the rate of the fp32 4x4x1 per value of k.  v_mfma_f32_16x16x32_bf16 with the four
+// columns in a quarter of its width was tried in its place: 8 instead of 16 instructions at hidden 512, but 500 instead of 250
+// cycles for the phase, forward 147 -> 171 us; at hidden 1024 its operands no longer fit the 168 registers.)
+// ------------------------------------------------------------------------------------------------
+typedef short fbf16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <int I, int E, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+template <int N_, int UW> struct FwdhbShape {
+    static constexpr int N = N_, NB = N / UW, Kw = N / 8, NRK = Kw >= 64 ? Kw / 64 : 1, NAB = Kw >= 64 ? 16 : Kw / 4;
+    static constexpr int NSET = UW / 16, NEH = UW / 16, THREADS = (8 + 2 * NEH) * 64;
+    static constexpr int ROW = 64 * NSET, RS = ROW + 4; // a (wave, column) row of the partial-sum image, padded
+    static constexpr size_t LDS = sizeof(float) * 2 * 2 * 8 * 4 * RS;
+};
+struct FwdhbArgs {
+    const uint2 *Ufwd6b;
+    const float *W, *bias;
+    float *H;
+    unsigned short *Hb;
+    float *C, *G;
+    const int32_t *xi;
+    unsigned *Hxb; // ring, as 32-bit words (two bf16 each)
+    unsigned *cnt, *abortp;
+    unsigned epoch;
+    int ring_base, S, B, NG, pinned;
+    unsigned long long *stamps;
+};
+__device__ __forceinline__ bool hxb_ready(const u32x2_t &v) { return v.x != HX_SENT && v.y != HX_SENT; }
+__device__ __forceinline__ unsigned hxb_canon(unsigned v) { return v == HX_SENT ? 0x7FC07FC0u : v; }
+template <int N_, int UW, bool FAST, bool STAMP = false>
+__global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf16(const FwdhbArgs p) {
+    using Sh = FwdhbShape<N_, UW>;
+    constexpr int N = N_, G4 = 4 * N, NB = Sh::NB, Kw = Sh::Kw, NRK = Sh::NRK, NAB = Sh::NAB, NSET = Sh::NSET, NEH = Sh::NEH, RS = Sh::RS;
+    static_assert((N == 256 || N == 512 || N == 1024) && (UW == 16 || UW == 32), "bf16 two-half forward form: shapes");
+    extern __shared__ __attribute__((aligned(16))) float red_[]; // [half][step parity][wave][column][RS]: [4*unit + gate]
+    __shared__ int s_abort;
+    __shared__ unsigned s_done[2][2];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int NG = p.NG;
+    int kb, g;
+    const int dbg = p.pinned >> 8; // timing experiments (LSTM_HIP_FWDHB_CFG)
+    if (p.pinned & 1) { // 8 * NB workgroups launched, workgroup i on XCD i % 8: group g = the workgroups of XCD g
+        g = (int)blockIdx.x & 7, kb = (int)blockIdx.x >> 3;
+        if (g >= NG) return;
+    } else {
+        kb = (int)blockIdx.x / NG, g = (int)blockIdx.x % NG;
+    }
+    const int S = p.S, B = p.B, ring_base = p.ring_base;
+    // diagnostics (LSTM_HIP_DEBUG_STAMPS): lane 0 of waves 3 and 8 of workgroups (0, 0) and (NB/2, 0); slots as in k_fwd_persistent6
+    unsigned long long *stq = STAMP && g == 0 && (kb == 0 || kb == NB / 2) && l == 0 && (w == 3 || w == 8) ? p.stamps + (size_t)(kb ? 1 : 0) * S * 16 : nullptr;
+#define HSTAMPQ(k) if (STAMP && stq) stq[(size_t)t * 16 + (k)] = __builtin_amdgcn_s_memtime();
+    const __amdgpu_buffer_rsrc_t rH = make_rsrc(p.H, (size_t)S * N * B * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(p.Hxb, (size_t)HX_RING * N * B * sizeof(unsigned short));
+    unsigned *xcc_tab = p.cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
+    if (tid == 0) {
+        s_abort = 0;
+        s_done[0][0] = s_done[0][1] = s_done[1][0] = s_done[1][1] = 0;
+        if (XCD_LOCAL) {
+            __hip_atomic_store(xcc_tab + kb, (p.epoch << 4) | (__builtin_amdgcn_s_getreg(6164) & 15u), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // visible before anything this workgroup publishes
+        }
+    }
+    __syncthreads();
+    auto give_up = [&]() {
+        if (l == 0) {
+            __hip_atomic_store(p.abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    if (w < 8) {
+        // ---------------- waves 0-7: the product, half A then half B ----------------
+        const int lb = l >> 2, li = l & 3; // lane = 4*block + i
+        const bool ld_lane = lb < NAB;     // N = 256: blocks 8-15 have nothing to fetch (their registers read as complete)
+        uint2 wq[NRK][NSET][NAB];
+#pragma unroll
+        for (int r = 0; r < NRK; r++)
+#pragma unroll
+            for (int sx = 0; sx < NSET; sx++)
+#pragma unroll
+                for (int ab = 0; ab < NAB; ab++)
+                    wq[r][sx][ab] = p.Ufwd6b[(((((size_t)kb * 8 + w) * NRK + r) * NSET + sx) * NAB + ab) * 64 + l];
+#pragma unroll
+        for (int r = 0; r < NRK; r++)
+#pragma unroll
+            for (int sx = 0; sx < NSET; sx++)
+#pragma unroll
+                for (int ab = 0; ab < NAB; ab++) asm volatile("" ::"v"(wq[r][sx][ab].x), "v"(wq[r][sx][ab].y)); // complete before the loop
+        int colv[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            const int c = 8 * g + 4 * hf + li;
+            colv[hf] = c < B ? c : B - 1;
+        }
+        // h_0 of both halves (plain fp32 window state in H, rounded here); later fragments come from the ring
+        u32x2_t bvq[2][NRK];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int r = 0; r < NRK; r++) {
+                bvq[hf][r] = u32x2_t{0u, 0u};
+                if (ld_lane) {
+                    const float4 f = ld_sc1(rH, (int)((((size_t)colv[hf]) * N + Kw * w + 64 * r + 4 * lb) * sizeof(float)));
+                    bvq[hf][r] = u32x2_t{pack_bf16x2(f.x, f.y), pack_bf16x2(f.z, f.w)};
+                }
+            }
+        for (int t = 1; t < S; t++) {
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                if (hf == 0) { HSTAMPQ(8) }
+                u32x2_t bv[NRK];
+                bool have = true;
+#pragma unroll
+                for (int r = 0; r < NRK; r++) {
+                    bv[r] = bvq[hf][r];
+                    have = have && hxb_ready(bv[r]);
+                }
+                if (t > 1 && !__all(have)) { // the fragment requested ahead came back incomplete: fetch until no word is the sentinel
+                    const int slot = (t - 1 + ring_base) & (HX_RING - 1);
+                    const int off = (int)((((size_t)slot * B + colv[hf]) * N + Kw * w + 4 * lb) * sizeof(unsigned short));
+                    bool ok = false;
+                    for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                        bool gd = true;
+#pragma unroll
+                        for (int r = 0; r < NRK; r++) {
+                            bv[r] = ld_lane ? __builtin_amdgcn_raw_buffer_load_b64(rX, off + 128 * r, 0, 16) : u32x2_t{0u, 0u};
+                            gd = gd && hxb_ready(bv[r]);
+                        }
+                        if (__all(gd)) {
+                            ok = true;
+                            break;
+                        }
+                        if ((spins & 255) == 255 && __hip_atomic_load(p.abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    }
+                    if (!ok) {
+                        give_up();
+                        return;
+                    }
+                }
+                if (hf == 0) { HSTAMPQ(9) } else { HSTAMPQ(5) }
+                // the OTHER half's next fragment -- (t, B) after A's product, (t+1, A) after B's -- is requested behind the matrix
+                // instructions and looked at when that half is next
+                const int nslot = (t - 1 + hf + ring_base) & (HX_RING - 1);
+                const int noff = (int)((((size_t)nslot * B + colv[hf ^ 1]) * N + Kw * w + 4 * lb) * sizeof(unsigned short));
+                const bool req = hf == 0 ? t > 1 : t + 1 < S;
+                f32x4 acc[NSET][2];
+#pragma unroll
+                for (int sx = 0; sx < NSET; sx++) acc[sx][0] = acc[sx][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!(dbg & 1))
+#pragma unroll
+                for (int r = 0; r < NRK; r++) {
+                    const fbf16x4_t av = __builtin_bit_cast(fbf16x4_t, bv[r]);
+                    static_for<0, NAB / 2>([&](auto ic) {
+                        constexpr int ab = 2 * decltype(ic)::value;
+#pragma unroll
+                        for (int sx = 0; sx < NSET; sx++) {
+                            acc[sx][0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av, __builtin_bit_cast(fbf16x4_t, wq[r][sx][ab]), acc[sx][0], 4, ab, 0);
+                            acc[sx][1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av, __builtin_bit_cast(fbf16x4_t, wq[r][sx][ab + 1]), acc[sx][1], 4, ab + 1, 0);
+                        }
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (req) {
+#pragma unroll
+                    for (int r = 0; r < NRK; r++)
+                        bvq[hf ^ 1][r] = ld_lane ? __builtin_amdgcn_raw_buffer_load_b64(rX, noff + 128 * r, 0, 16) : u32x2_t{0u, 0u};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (hf == 0) { HSTAMPQ(10) } else { HSTAMPQ(6) }
+                // lane (unit u, gate j), register i = column i of the half: one row of the image per (wave, column).  No workgroup
+                // barrier: the gating waves of the half count the images in (LDS operations of a wave execute in order)
+                float *rp = red_ + (size_t)(hf * 2 + (t & 1)) * (8 * 4 * RS);
+#pragma unroll
+                for (int sx = 0; sx < NSET; sx++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) rp[(w * 4 + i) * RS + 64 * sx + l] = acc[sx][0][i] + acc[sx][1][i];
+                asm volatile("" ::: "memory");
+                if (l == 0) __hip_atomic_fetch_add(&s_done[hf][t & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (hf == 0) { HSTAMPQ(11) } else { HSTAMPQ(7) }
+            }
+        }
+    } else {
+        // ---------------- gating waves: NEH per half, 16 units each; lane = column*16 + unit ----------------
+        const int hf = (w - 8) / NEH, uh = (w - 8) % NEH;
+        __builtin_amdgcn_s_setprio(3);
+        const int gc = l >> 4, gu = l & 15;
+        const int col = 8 * g + 4 * hf + gc, colc = col < B ? col : B - 1;
+        const int j = UW * kb + 16 * uh + gu;
+        float bs[4], cprev, wx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++) bs[gt] = p.bias[gt * N + j];
+        cprev = p.C[(size_t)colc * N + j];
+        int xnext = p.xi[1 * B + colc];
+        bool local_pub = false;
+        const float *rp0 = red_ + (size_t)(hf * 2) * (8 * 4 * RS) + gc * RS + 64 * uh + 4 * gu;
+        for (int t = 1; t < S; t++) {
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) wx[gt] = 0.f;
+            if (xnext >= 0 && !(dbg & 4)) {
+#pragma unroll
+                for (int gt = 0; gt < 4; gt++) wx[gt] = p.W[(size_t)xnext * G4 + gt * N + j]; // R/lstm.cc:176 with a one-hot x
+            }
+            if (t + 1 < S) xnext = p.xi[(t + 1) * B + colc];
+            HSTAMPQ(0)
+            {   // all eight partial-sum images of this half and step are in LDS
+                bool in = false;
+                for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
+                    in = __hip_atomic_load(&s_done[hf][t & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 8u * (unsigned)((t + 1) / 2);
+                    if (in || __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!in) {
+                    give_up();
+                    return;
+                }
+                asm volatile("" ::: "memory");
+            }
+            const float *rp = rp0 + (t & 1) * (8 * 4 * RS);
+            HSTAMPQ(1)
+            if (XCD_LOCAL && t == 2) { // every workgroup of the group has published h_1, hence its XCC id before it
+                unsigned mine = 0;
+                bool same = true;
+                if (l < NB) {
+                    mine = __hip_atomic_load(xcc_tab + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    same = (mine >> 4) == p.epoch;
+                }
+                const unsigned first = __builtin_amdgcn_readfirstlane(mine);
+                if (l < NB) same = same && mine == first;
+                local_pub = XCD_FORCE_LOCAL || __all(same);
+            }
+            float4 uhs = *reinterpret_cast<const float4 *>(rp); // the four gates of (unit, column), wave 0's K-slice
+#pragma unroll
+            for (int ww = 1; ww < 8; ww++) {
+                const float4 v = *reinterpret_cast<const float4 *>(rp + ww * 4 * RS);
+                uhs.x += v.x;
+                uhs.y += v.y;
+                uhs.z += v.z;
+                uhs.w += v.w;
+            }
+            const float pre0 = (wx[0] + uhs.x) + bs[0], pre1 = (wx[1] + uhs.y) + bs[1]; // R/lstm.cc:176
+            const float pre2 = (wx[2] + uhs.z) + bs[2], pre3 = (wx[3] + uhs.w) + bs[3];
+            const float ig = p_sigm<FAST>(pre0), og = p_sigm<FAST>(pre1), fg = p_sigm<FAST>(pre2); // :179
+            const float ug_ = p_tanh<FAST>(pre3);                                                 // :182
+            const float cv = p_tanh<FAST>(ig * ug_ + fg * cprev);                                 // :185-189
+            const float hv = og * cv;                                                             // :192
+            cprev = cv;
+            float4 h4; // four consecutive units sit in the four lanes of a quad
+            h4.x = dpp_f<0x00>(hv);
+            h4.y = dpp_f<0x55>(hv);
+            h4.z = dpp_f<0xAA>(hv);
+            h4.w = dpp_f<0xFF>(hv);
+            HSTAMPQ(2)
+            // the reset this wave issued a step ago (and every older store) has completed before h_t can be seen
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            HSTAMPQ(3)
+            if ((gu & 3) == 0 && col < B) {
+                const u32x2_t hp = {hxb_canon(pack_bf16x2(h4.x, h4.y)), hxb_canon(pack_bf16x2(h4.z, h4.w))};
+                const u32x2_t sent = {HX_SENT, HX_SENT};
+                const size_t e_pub = ((size_t)((t + ring_base) & (HX_RING - 1)) * B + col) * N + j;
+                const size_t e_rst = ((size_t)((t + 2 + ring_base) & (HX_RING - 1)) * B + col) * N + j;
+                if (XCD_LOCAL && local_pub) {
+                    *reinterpret_cast<u32x2_t *>(reinterpret_cast<unsigned short *>(p.Hxb) + e_pub) = hp;
+                    *reinterpret_cast<u32x2_t *>(reinterpret_cast<unsigned short *>(p.Hxb) + e_rst) = sent;
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b64(hp, rX, (int)(e_pub * sizeof(unsigned short)), 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b64(sent, rX, (int)(e_rst * sizeof(unsigned short)), 0, 16);
+                }
+                // off the chain: the plain copies the time-batched products read (fp32 H, bf16 Hb)
+                if (!(dbg & 2)) *reinterpret_cast<u32x2_t *>(p.Hb + ((size_t)t * B + col) * N + j) = u32x2_t{pack_bf16x2(h4.x, h4.y), pack_bf16x2(h4.z, h4.w)};
+                if (!(dbg & 2)) *reinterpret_cast<float4 *>(p.H + ((size_t)t * B + col) * N + j) = h4;
+            }
+            if (col < B && !(dbg & 2)) {
+                float *gcp = p.G + ((size_t)t * B + col) * G4 + j;
+                gcp[0] = ig;
+                gcp[N] = og;
+                gcp[2 * N] = fg;
+                gcp[3 * N] = ug_;
+                p.C[((size_t)t * B + col) * N + j] = cv;
+            }
+            HSTAMPQ(4)
+        }
+    }
+#undef HSTAMPQ
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward recurrence, two half-groups per workgroup (N = 512 / 256, 8-column groups; the backward twin of
 // k_fwd_persistent6): grid (N/16, ceil(B/8)), 768 threads.  The eight columns of workgroup (kb, g) are two independent
 // recurrences of four columns, A and B, advanced alternately: while A's step is summed, computed elementwise and handed
@@ -1963,6 +2263,7 @@ struct BwdsbArgs {
     unsigned *cnt, *abortp;
     unsigned epoch;
     int ring_base, S, B, NG, pinned, cfg;
+    unsigned long long *stamps;
 };
 // UW = units per workgroup: 16, or 32 where a group of N/16 workgroups would not fit one XCD (hidden 1024: 32 workgroups of
 // 128 gate rows each, a quarter of the chip per 8 columns, but every hand-off stays inside one L2 -- measured at hidden 512,
@@ -1992,7 +2293,8 @@ __device__ __forceinline__ bool bwdsb_ready(const float4 &v, unsigned phase) {
     return ((__float_as_uint(v.x) & __float_as_uint(v.y) & __float_as_uint(v.z) & __float_as_uint(v.w) & 1u) == phase) &&
            (((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) & 1u) == phase);
 }
-template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_bf16(const BwdsbArgs p) {
+template <int N_, int UW, bool STAMP = false>
+__global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_bf16(const BwdsbArgs p) {
     using Sh = BwdsbShape<N_, UW>;
     constexpr int N = N_, G4 = 4 * N, NB = Sh::NB, NLD = NB / 4, KK = Sh::KK, NR = Sh::NR, NS = Sh::NS, NPW = Sh::NPW, NEH = Sh::NEH;
     static_assert((N == 256 || N == 512 || N == 1024) && (UW == 16 || UW == 32) && NB % 4 == 0, "bf16 scatter form: shapes");
@@ -2010,6 +2312,9 @@ template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THRE
     }
     const int S = p.S, B = p.B, ring_base = p.ring_base;
     float *Qx = p.Qx;
+    // diagnostics (LSTM_HIP_DEBUG_STAMPS): lane 0 of waves 3 and 8 of workgroups (0, 0) and (NB/2, 0); slots as in k_bwd_scatter
+    unsigned long long *stq = STAMP && g == 0 && (kb == 0 || kb == NB / 2) && l == 0 && (w == 3 || w == 8) ? p.stamps + (size_t)(kb ? 1 : 0) * S * 16 : nullptr;
+#define HSTAMPQ(k) if (STAMP && stq) stq[(size_t)t * 16 + (k)] = __builtin_amdgcn_s_memtime();
     const __amdgpu_buffer_rsrc_t rQ = make_rsrc(Qx, bwdsb_ring_floats(N, UW, B) * sizeof(float));
     unsigned *xcc_tab = p.cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
     if (tid == 0) {
@@ -2062,11 +2367,13 @@ template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THRE
         for (int t = S - 1; t >= 2; t--) {
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
+                if (hf == 0) { HSTAMPQ(8) }
                 if (!lds_wait(&s_done[hf][t & 1], (unsigned)(NEH * ((S - 1 - t) / 2 + 1)))) {
                     give_up();
                     return;
                 }
                 if (!active) continue;
+                if (hf == 0) { HSTAMPQ(9) } else { HSTAMPQ(5) }
                 bf16x4_t av[NR]; // column lj, k = 4*(16r + lb) .. +3
 #pragma unroll
                 for (int r = 0; r < NR; r++)
@@ -2089,6 +2396,9 @@ template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THRE
                         for (int r = 0; r < NR; r++) { SB4(r, 0) SB4(r, 4) SB4(r, 8) SB4(r, 12) }
                     }
 #undef SB4
+                    if (sx == NS - 1) {
+                        if (hf == 0) { HSTAMPQ(10) } else { HSTAMPQ(6) }
+                    }
                     float4 q;
                     q.x = bwdsb_mark((c0[0] + c1[0]) + (c2[0] + c3[0]), phase);
                     q.y = bwdsb_mark((c0[1] + c1[1]) + (c2[1] + c3[1]), phase);
@@ -2105,6 +2415,9 @@ template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THRE
                     } else {
                         st_sc1(q, rQ, e_pub * (int)sizeof(float));
                         if (!BWDSB_TAGGED) st_sc1(sent, rQ, e_rst * (int)sizeof(float));
+                    }
+                    if (sx == NS - 1) {
+                        if (hf == 0) { HSTAMPQ(11) } else { HSTAMPQ(7) }
                     }
                 }
             }
@@ -2127,6 +2440,7 @@ template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THRE
         };
         fetch(S - 1);
         for (int t = S - 1; t >= 1; t--) {
+            HSTAMPQ(0)
             float dhn = 0.0f;
             if (t < S - 1) {
                 // Q_{t+1}: this lane's piece = sources 4i + (l >> 4), unit 16*uh + (l & 15), the four columns
@@ -2179,6 +2493,7 @@ template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THRE
                 const float keep = (q & 2) ? z1 : z0, send = (q & 2) ? z0 : z1;
                 dhn = keep + xchg_half32(send, l);
             }
+            HSTAMPQ(1)
             if (XCD_LOCAL && t == S - 2) { // every workgroup of the group has published Q_{S-1}, its XCC id before it
                 unsigned mine = 0;
                 bool same = true;
@@ -2200,6 +2515,7 @@ template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THRE
             const float d_f = (dcv * cp) * (fg * (1.0f - fg));  // :240,244
             const float d_u = (dcv * ig) * (1.0f - ug * ug);    // :241,247
             dcn = dcv * fg;                                     // :256
+            HSTAMPQ(2)
             {   // dg_t, rounded to bfloat16, for this workgroup's product waves: [column][k = gate*UW + unit]
                 unsigned short *dp = &dgl[hf][t & 1][cc * KK + uu];
                 dp[0] = __builtin_bit_cast(unsigned short, (__bf16)d_i);
@@ -2209,6 +2525,7 @@ template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THRE
                 asm volatile("" ::: "memory");
                 if (l == 0) __hip_atomic_fetch_add(&s_done[hf][t & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            HSTAMPQ(3)
             // off the chain: the plain fp32 DG the dU / dW / db launches read afterwards (4x4 DPP transpose, one 16-byte store)
             const int ta = jj & 3, tq = jj >> 2;
             float t0 = d_i, t1 = d_o, t2 = d_f, t3 = d_u;
@@ -2236,9 +2553,11 @@ template <int N_, int UW> __global__ __launch_bounds__((BwdsbShape<N_, UW>::THRE
                 const float4 v = {t0, t1, t2, t3};
                 *reinterpret_cast<float4 *>(p.DG + ((size_t)t * B + ecol) * G4 + ta * N + UW * kb + 16 * uh + 4 * tq) = v;
             }
+            HSTAMPQ(4)
             if (t >= 2 && !(p.cfg & 8)) fetch(t - 1);
         }
     }
+#undef HSTAMPQ
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2939,6 +3258,77 @@ static int fwd_bf16_cols(int N, int B, int n_cus) {
                ? 8
                : 16;
 }
+// ---- bf16 two-half forward form (k_fwd_halves_bf16) ----
+int fwd_halves_bf16_units(int N) { return N == 1024 ? 32 : 16; }
+// Ufwd6b[kb][w][r][set][ab][l] = bf16 x 4 { U[gate (l & 3) of unit UW*kb + 16*set + (l >> 2)][k = Kw*w + 64*r + 4*ab + e], e = 0..3 }
+__global__ __launch_bounds__(256) void k_pack_Ufwd6_bf16(const float *__restrict__ U, uint2 *__restrict__ img, int N, int UW) {
+    const int G4 = 4 * N, Kw = N / 8, NRK = Kw >= 64 ? Kw / 64 : 1, NAB = Kw >= 64 ? 16 : Kw / 4, NSET = UW / 16;
+    const size_t total = (size_t)N * N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(e & 63);
+        size_t q = e >> 6;
+        const int ab = (int)(q % NAB);
+        q /= NAB;
+        const int sx = (int)(q % NSET);
+        q /= NSET;
+        const int r = (int)(q % NRK);
+        q /= NRK;
+        const int w = (int)(q % 8), kb = (int)(q / 8);
+        const int row = (l & 3) * N + UW * kb + 16 * sx + (l >> 2), k = Kw * w + 64 * r + 4 * ab;
+        float v[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) v[x] = U[(size_t)(k + x) * G4 + row];
+        img[e] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+}
+void pack_Ufwd6_bf16(const float *U, void *img, int N, hipStream_t st) {
+    const size_t n = (size_t)N * N;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_pack_Ufwd6_bf16, dim3(blocks), dim3(256), 0, st, U, reinterpret_cast<uint2 *>(img), N, fwd_halves_bf16_units(N));
+}
+size_t fwd_halves_bf16_ring_halfwords(int N, int B) { return (size_t)HX_RING * N * B; }
+#define FHB_DISPATCH(GO)                  \
+    do {                                  \
+        if (N == 1024) GO(1024, 32);      \
+        else if (N == 512) GO(512, 16);   \
+        else GO(256, 16);                 \
+    } while (0)
+bool fwd_halves_bf16_supported(int N, int B, int n_cus) {
+    if (N != 256 && N != 512 && N != 1024) return false;
+    if (B % 4 != 0) return false; // 8-byte ring pieces and Hb rows
+    const size_t grid = (size_t)(N / fwd_halves_bf16_units(N)) * ((B + 7) / 8);
+    int per_cu = 0;
+#define GO(n, u)                                                                                                                  \
+    per_cu = blocks_per_cu(k_fwd_halves_bf16<n, u, false>, FwdhbShape<n, u>::THREADS, FwdhbShape<n, u>::LDS) > 0 &&               \
+                     blocks_per_cu(k_fwd_halves_bf16<n, u, true>, FwdhbShape<n, u>::THREADS, FwdhbShape<n, u>::LDS) > 0           \
+                 ? 1                                                                                                              \
+                 : 0
+    FHB_DISPATCH(GO);
+#undef GO
+    return per_cu >= 1 && grid <= (size_t)n_cus;
+}
+void fwd_halves_bf16(const void *Ufwd6b, const float *W, const float *bias, float *H, unsigned short *Hb, float *C, float *G,
+                     const int32_t *xi, void *Hxb, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S,
+                     int B, bool fast, int n_cus, hipStream_t st, unsigned long long *stamps) {
+    const int NB = N / fwd_halves_bf16_units(N), NG = (B + 7) / 8;
+    static const bool no_pin = getenv("LSTM_HIP_NO_PIN") && atoi(getenv("LSTM_HIP_NO_PIN")); // A/B
+    static const int dbg = getenv("LSTM_HIP_FWDHB_CFG") ? atoi(getenv("LSTM_HIP_FWDHB_CFG")) : 0; // timing experiments only
+    const int pinned = (NG < 8 && 8 * NB <= n_cus && !no_pin ? 1 : 0) | (dbg << 8);
+    const dim3 grid((pinned & 1) ? 8 * NB : NB * NG);
+    const FwdhbArgs args = {reinterpret_cast<const uint2 *>(Ufwd6b), W, bias, H, Hb, C, G, xi, reinterpret_cast<unsigned *>(Hxb), cnt, abortp,
+                            epoch, ring_base, S, B, NG, pinned, stamps};
+#define GO(n, u)                                                                                                               \
+    do {                                                                                                                       \
+        if (stamps) hipLaunchKernelGGL((k_fwd_halves_bf16<n, u, false, true>), grid, dim3(FwdhbShape<n, u>::THREADS), (FwdhbShape<n, u>::LDS), st, args); \
+        else if (fast) hipLaunchKernelGGL((k_fwd_halves_bf16<n, u, true>), grid, dim3(FwdhbShape<n, u>::THREADS), (FwdhbShape<n, u>::LDS), st, args); \
+        else hipLaunchKernelGGL((k_fwd_halves_bf16<n, u, false>), grid, dim3(FwdhbShape<n, u>::THREADS), (FwdhbShape<n, u>::LDS), st, args);     \
+    } while (0)
+    FHB_DISPATCH(GO);
+#undef GO
+}
+#undef FHB_DISPATCH
+
 void fwd_persistent_bf16(const void *Ufwd16, const float *W, const float *bias, float *H, unsigned short *Hb, float *C,
                          float *G, const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B,
                          bool fast, hipStream_t st, int n_cus) {
@@ -3057,14 +3447,17 @@ bool bwd_scatter_bf16_supported(int N, int B, int n_cus) {
     return per_cu >= 1 && grid <= (size_t)n_cus;
 }
 void bwd_scatter_bf16(const void *Ubwd6b, float *DG, const float *DHy, const float *G, const float *C, float *Qx, unsigned *cnt,
-                      unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int n_cus, hipStream_t st) {
+                      unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int n_cus, hipStream_t st,
+                      unsigned long long *stamps) {
     const int NB = N / bwd_scatter_bf16_units(N), NG = (B + 7) / 8;
     static const int spread = getenv("LSTM_HIP_BWD_SPREAD") && atoi(getenv("LSTM_HIP_BWD_SPREAD")) ? 1 : 0;
     const int pinned = bwdsb_pinned(N, B, n_cus) && !spread;
     static const int cfg = getenv("LSTM_HIP_BWDSB_CFG") ? atoi(getenv("LSTM_HIP_BWDSB_CFG")) : 0; // timing experiments only
     const dim3 grid(pinned ? 8 * NB : NB * NG);
-    const BwdsbArgs args = {reinterpret_cast<const uint2 *>(Ubwd6b), DG, DHy, G, C, Qx, cnt, abortp, epoch, ring_base, S, B, NG, pinned, cfg};
-    if (N == 1024) hipLaunchKernelGGL((k_bwd_scatter_bf16<1024, 32>), grid, dim3(BwdsbShape<1024, 32>::THREADS), 0, st, args);
+    const BwdsbArgs args = {reinterpret_cast<const uint2 *>(Ubwd6b), DG, DHy, G, C, Qx, cnt, abortp, epoch, ring_base, S, B, NG, pinned, cfg, stamps};
+    if (N == 1024 && stamps) hipLaunchKernelGGL((k_bwd_scatter_bf16<1024, 32, true>), grid, dim3(BwdsbShape<1024, 32>::THREADS), 0, st, args);
+    else if (N == 1024) hipLaunchKernelGGL((k_bwd_scatter_bf16<1024, 32>), grid, dim3(BwdsbShape<1024, 32>::THREADS), 0, st, args);
+    else if (N == 512 && stamps) hipLaunchKernelGGL((k_bwd_scatter_bf16<512, 16, true>), grid, dim3(BwdsbShape<512, 16>::THREADS), 0, st, args);
     else if (N == 512) hipLaunchKernelGGL((k_bwd_scatter_bf16<512, 16>), grid, dim3(BwdsbShape<512, 16>::THREADS), 0, st, args);
     else hipLaunchKernelGGL((k_bwd_scatter_bf16<256, 16>), grid, dim3(BwdsbShape<256, 16>::THREADS), 0, st, args);
 }

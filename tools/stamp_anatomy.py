@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 import lstm_hip  # noqa: E402
 from bench import synthetic_text  # noqa: E402
 
-N, S, B = 512, 100, 64
+N, S, B = (int(v) for v in os.environ.get("STAMP_SHAPE", "512,100,64").split(","))   # STAMP_SHAPE=1024,100,16 STAMP_FLAGS=16: configs[4]
 L = lstm_hip.Lstm(N, S, B, flags=lstm_hip.DEBUG_STAMPS | int(os.environ.get("STAMP_FLAGS", "0")))
 L.set_params(lstm_hip.init_params(lstm_hip.MT19937Normal(1), N))
 text = synthetic_text(200000)
