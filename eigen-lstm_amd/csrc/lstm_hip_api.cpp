@@ -269,7 +269,8 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
     h->fwd_epoch++;
     if (h->bf16) {
         if (!h->packed16) {
-            RUN(K_PACK_U, (pack_U_bf16(h->P + h->pl.U, h->Ufwd16, h->Ubwd16, N, h->st),
+            // (the one-recurrence forms' images only where one of them runs)
+            RUN(K_PACK_U, (h->fwd_halves16 && h->bwd_scatter16 ? (void)0 : pack_U_bf16(h->P + h->pl.U, h->Ufwd16, h->Ubwd16, N, h->st),
                            h->bwd_scatter16 ? pack_U6_bf16(h->P + h->pl.U, h->Ubwd6b, N, h->st) : (void)0,
                            h->fwd_halves16 ? pack_Ufwd6_bf16(h->P + h->pl.U, h->Ufwd6b, N, h->st) : (void)0));
             h->packed16 = true;
@@ -374,6 +375,10 @@ int do_backward(lstm_hip_ctx *h) {
     // the dW pass and dWhy = dY H^T while the recurrence runs (one workgroup per CU leaves room), the dW / db sums beside
     // the dU product.  (Profiling runs keep everything on `st`, one timed launch after the other.)
     const bool side = h->bwd_halves && !fused && h->side_stream && !h->comm && !h->profiling;
+    // (Not for the bf16 scatter form, although its pinned launch leaves most of the chip idle -- configs[4]: 64 of 256 CUs.
+    // Measured, kernel trace: of the side stream's launches only the one-workgroup column sort ran beside the recurrence; the
+    // next one started and then sat until the recurrence ended, because its workgroups are dealt to the XCDs in turn and the
+    // two XCDs the recurrence fills have no room for the ones they are dealt.  Window 0.6993 -> 0.6955 ms: dropped.)
     if (side) {
         HIP_TRY(hipEventRecord(h->ev_fork, h->st));
         HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));

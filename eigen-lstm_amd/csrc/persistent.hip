@@ -1282,7 +1282,10 @@ __global__ __launch_bounds__(512) void k_fwd_persistent2_bf16(const u32x4 *__res
 // (v_mfma_f32_4x4x4_16b_bf16 issues in 16 cycles -- stamps: 16 of them 232-264 cycles, 64 of them 1 450-1 800 with the
 // SIMD's other product wave beside -- twice the rate of the fp32 4x4x1 per value of k.  v_mfma_f32_16x16x32_bf16 with the four
 // columns in a quarter of its width was tried in its place: 8 instead of 16 instructions at hidden 512, but 500 instead of 250
-// cycles for the phase, forward 147 -> 171 us; at hidden 1024 its operands no longer fit the 168 registers.)
+// cycles for the phase, forward 147 -> 171 us; at hidden 1024 its operands no longer fit the 168 registers.  Hidden 1024 as ONE
+// 8-column recurrence per workgroup on 16x16x32 -- half its width used, 32 instructions a step and wave -- measured 262 us against
+// this form's 252: what the two halves hide behind each other is worth more than the matrix time saved.  Without any matrix
+// instruction the hidden-1024 launch takes 189 us, the hidden-512 one 147.)
 // ------------------------------------------------------------------------------------------------
 typedef short fbf16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
