@@ -2281,7 +2281,7 @@ __host__ __device__ inline size_t bwdsb_ring_floats(int N, int UW, int B) {
     return (size_t)HX_RING * ((B + 7) / 8) * 2 * nb * nb * (4 * UW);
 }
 // Hand-off without a reset store (BWDSB_TAGGED): a published partial sum carries the parity of its slot's use count in its last
-// mantissa bit (a perturbation of at most one fp32 ulp of a partial sum whose operands were rounded to bf16), so a consumer
+// mantissa bit (the consumer clears it again: a partial sum, whose operands were rounded to bf16, loses its last bit), so a consumer
 // tells this use of the slot from the previous one by that bit, in all four words of a 16-byte piece, and nobody has to write
 // the sentinel back: half the ring's write traffic.  The ring starts as all ones (parity 1), the first use publishes parity 0.
 #ifndef BWDSB_TAGGED
@@ -2291,6 +2291,7 @@ __device__ __forceinline__ float bwdsb_mark(float v, unsigned phase) {
     if (!BWDSB_TAGGED) return hx_canon(v);
     return __uint_as_float((__float_as_uint(v) & ~1u) | phase);
 }
+__device__ __forceinline__ float bwdsb_value(float v) { return BWDSB_TAGGED ? __uint_as_float(__float_as_uint(v) & ~1u) : v; }
 __device__ __forceinline__ bool bwdsb_ready(const float4 &v, unsigned phase) {
     if (!BWDSB_TAGGED) return hx_ready(v);
     return ((__float_as_uint(v.x) & __float_as_uint(v.y) & __float_as_uint(v.z) & __float_as_uint(v.w) & 1u) == phase) &&
@@ -2481,13 +2482,14 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
                     give_up();
                     return;
                 }
-                float4 sm = v[0];
+                // the phase bit is cleared before the sum: what is added does not depend on which use of the slot this is
+                float4 sm = {bwdsb_value(v[0].x), bwdsb_value(v[0].y), bwdsb_value(v[0].z), bwdsb_value(v[0].w)};
 #pragma unroll
                 for (int i = 1; i < NLD; i++) {
-                    sm.x += v[i].x;
-                    sm.y += v[i].y;
-                    sm.z += v[i].z;
-                    sm.w += v[i].w;
+                    sm.x += bwdsb_value(v[i].x);
+                    sm.y += bwdsb_value(v[i].y);
+                    sm.z += bwdsb_value(v[i].z);
+                    sm.w += bwdsb_value(v[i].w);
                 }
                 const int q = l >> 4;
                 const float k0 = (q & 1) ? sm.y : sm.x, k1 = (q & 1) ? sm.w : sm.z;

@@ -11,8 +11,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(lstm_hip, text, N, S, B, windows, lr, chunk=1000):
-    L = lstm_hip.Lstm(N, S, B)
+def _run(lstm_hip, text, N, S, B, windows, lr, chunk=1000, flags=0):
+    L = lstm_hip.Lstm(N, S, B, flags=flags)
     L.set_params(lstm_hip.init_params(lstm_hip.MT19937Normal(1), N))
     L.set_text(text)
     L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
@@ -34,6 +34,23 @@ def test_two_handles_same_seed_bit_identical(N, S, B, windows):
     text = synthetic_text(200_000, seed=0)
     l0, p0 = _run(lstm_hip, text, N, S, B, windows, 0.005)
     l1, p1 = _run(lstm_hip, text, N, S, B, windows, 0.005)
+    assert np.all(np.isfinite(l0))
+    assert np.array_equal(l0, l1), f"first differing window: {int(np.argmax(l0 != l1))}"
+    assert np.array_equal(p0, p1)
+
+
+@pytest.mark.parametrize("N,S,B,windows", [
+    (1024, 100, 16, 1500),  # BASELINE configs[4]: 32 units to a workgroup, two groups pinned to two XCDs
+    (512, 25, 64, 3000),    # eight groups, eight XCDs; odd number of hand-offs per launch (slot and phase walk)
+    (1024, 9, 64, 1000),    # hidden 1024, 64 streams: every CU holds a workgroup
+])
+def test_bf16_forms_two_handles_bit_identical(N, S, B, windows):
+    """The bf16 recurrences (k_fwd_halves_bf16, k_bwd_scatter_bf16): sentinel ring forward, phase-tagged ring backward."""
+    import lstm_hip
+    from bench import synthetic_text
+    text = synthetic_text(200_000, seed=0)
+    l0, p0 = _run(lstm_hip, text, N, S, B, windows, 0.005, flags=lstm_hip.BF16_RECURRENCE)
+    l1, p1 = _run(lstm_hip, text, N, S, B, windows, 0.005, flags=lstm_hip.BF16_RECURRENCE)
     assert np.all(np.isfinite(l0))
     assert np.array_equal(l0, l1), f"first differing window: {int(np.argmax(l0 != l1))}"
     assert np.array_equal(p0, p1)

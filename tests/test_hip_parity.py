@@ -783,7 +783,10 @@ def test_create_destroy_does_not_leak():
     L.close()
 
 
-@pytest.mark.parametrize("N,S,B", [(128, 6, 8), (256, 10, 24), (512, 12, 64), (1024, 4, 16)])
+# (256, 9, 72): 9 column groups, the unpinned placement; (512, 7, 16) / (1024, ...): fewer than 8 groups, one group pinned to
+# each XCD; (1024, 5, 64): hidden 1024 with 8 groups of 32 workgroups -- the whole chip, one workgroup per CU
+@pytest.mark.parametrize("N,S,B", [(128, 6, 8), (256, 10, 24), (256, 9, 72), (512, 12, 64), (512, 7, 16), (1024, 4, 16),
+                                   (1024, 5, 64)])
 def test_bf16_recurrence_matches_bf16_oracle(N, S, B, oracle32):
     """LSTM_HIP_BF16_RECURRENCE (BASELINE configs[4] semantics: bf16 MFMA operands in the two recurrent and the four
     time-batched products, fp32 accumulate and fp32 everything else) against the oracle in the same mode (those operands
@@ -811,6 +814,40 @@ def test_bf16_recurrence_matches_bf16_oracle(N, S, B, oracle32):
     assert max(rep.values()) <= 1e-2, rep
     # and it really is the bf16 model: closer to the bf16 oracle than the fp32 oracle is
     assert gu.max_rel(got["h"][-1], fw["h"][S - 1]) < 0.5 * gu.max_rel(fw32["h"][S - 1], fw["h"][S - 1]) + 1e-6
+
+
+@pytest.mark.parametrize("N,S,B", [(512, 5, 16), (1024, 6, 16), (256, 3, 8)])
+def test_bf16_forms_keep_their_rings_across_launches(N, S, B, oracle32):
+    """The bf16 recurrences hand data over through rings whose slot / phase numbering continues from launch to launch (odd
+    window lengths walk through every residue): the 1st, 2nd ... 9th forward + backward on one handle must each reproduce
+    the oracle's window, and the handle must not report a timed-out hand-off."""
+    import lstm_hip
+    P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=3 * N + S, scale=0.05)
+    oracle32.set_bf16_recurrence(True)
+    oracle32.set_bf16_products(True)
+    try:
+        fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
+        dref = oracle32.backward(N, 256, S, B, P, xi, ti, fw)
+    finally:
+        oracle32.set_bf16_recurrence(False)
+        oracle32.set_bf16_products(False)
+    L = lstm_hip.Lstm(N, S, B, flags=lstm_hip.BF16_RECURRENCE)
+    L.set_params(P)
+    first = None
+    for rep in range(9):
+        L.set_state(0, h0, c0)
+        L.set_window(xi, ti)
+        L.forward()
+        L.backward()
+        h, _ = L.get_state(S - 1)
+        g = L.get_grads()
+        assert gu.max_rel(h, fw["h"][S - 1]) <= 2e-3, rep
+        assert max(gu.grads_report(g, dref, N).values()) <= 1e-2, rep
+        if first is None:
+            first = (h.copy(), g.copy())
+        else:   # and bit-identical to the first launch: same sums in the same order, whatever the slot / phase
+            assert np.array_equal(h, first[0]) and np.array_equal(g, first[1]), rep
+    L.close()
 
 
 @pytest.mark.parametrize("bf16", [False, True])

@@ -12,3 +12,4 @@ def test_partial_sum_ring_slots_are_consistent_across_launches():
     spec.loader.exec_module(sim)
     for S in range(2, 130):
         sim.run(S, 7)
+        sim.run_tagged(S, 11)   # the bf16 form's reset-free variant (phase bit in the data)
