@@ -104,6 +104,7 @@ void fwd_halves_bf16(const void *Ufwd6b, const float *W, const float *bias, floa
                      const int32_t *xi, void *Hxb, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S,
                      int B, bool fast, int n_cus, hipStream_t st, unsigned long long *stamps);
 size_t bwd_scatter_bf16_ring_floats(int N, int B);
+int bwd_scatter_bf16_units(int N);
 int bwd_scatter_bf16_ring_advance(int base, int S);
 void bwd_scatter_bf16(const void *Ubwd6b, float *DG, const float *DHy, const float *G, const float *C, float *Qx, unsigned *cnt,
                       unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int n_cus, hipStream_t st,
@@ -174,7 +175,8 @@ void dW_sums(const float *DG, int T, int G4, float *dW, float *db, void *scratch
 void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
              hipStream_t st, float4 *Ubwd4 = nullptr, float4 *Ufwd4 = nullptr, const float *gpart = nullptr, int n_groups = 0,
              size_t group_stride = 0, size_t by_off = 0, const float *slabs = nullptr, int n_slabs = 0, size_t slab_stride = 0,
-             int half_forms = 0);
+             int half_forms = 0, void *u6b = nullptr, int u6_uw = 0, unsigned short *why_b = nullptr,
+             unsigned short *whyT_b = nullptr, size_t why_off = 0);
 
 // ---- window builder on the device (OV/lstm_eigen_opt/lstm.cc:190-213): x/target rings + flat copies,
 //      cursor advance, and the h/c carry (column 1 -> column 0).  Single workgroup.

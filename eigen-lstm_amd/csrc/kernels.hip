@@ -959,6 +959,10 @@ struct GradFold {
     const float *slabs;  // dU split-K slabs; null: dU is final in dP
     int n_slabs;
     size_t slab_stride; // floats
+    uint2 *u6b;         // bf16 path: the scatter-form backward image of U (persistent.hip, k_pack_U6_bf16), refreshed here; or null
+    int u6_uw;          // its units per workgroup
+    unsigned short *why_b, *whyT_b; // bf16 path: Why as bf16 in place order [hidden][256] and transposed [256][hidden]; or null
+    size_t why_off4, why_n4;        // float4 range of Why in the flat block
 };
 template <bool FOLD>
 __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *__restrict__ dP,
@@ -998,6 +1002,26 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *_
         p.w = adagrad1(p.w, d.w, m.w, lr);
         reinterpret_cast<float4 *>(P)[i] = p;
         reinterpret_cast<float4 *>(mem)[i] = m;
+        if (fold.why_b != nullptr && i >= fold.why_off4 && i < fold.why_off4 + fold.why_n4) {
+            auto b16 = [](float v) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v); };
+            const size_t f = 4 * (i - fold.why_off4); // Why[m + 256*kh], m = f % 256 .. +3
+            *reinterpret_cast<uint2 *>(fold.why_b + f) = uint2{b16(p.x) | (b16(p.y) << 16), b16(p.z) | (b16(p.w) << 16)};
+            const size_t m = f % 256, kh = f / 256;
+            fold.whyT_b[(m + 0) * N + kh] = (unsigned short)b16(p.x);
+            fold.whyT_b[(m + 1) * N + kh] = (unsigned short)b16(p.y);
+            fold.whyT_b[(m + 2) * N + kh] = (unsigned short)b16(p.z);
+            fold.whyT_b[(m + 3) * N + kh] = (unsigned short)b16(p.w);
+        }
+        if (fold.u6b != nullptr && i >= u_off4 && i < u_off4 + u_n4) {
+            // four consecutive gate rows of one hidden column are one 8-byte element of Ubwd6b (same index as k_pack_U6_bf16)
+            const size_t e = i - u_off4;
+            const int r = 4 * (int)(e % N), out = (int)(e / N), UW = fold.u6_uw;
+            const int gate = r / N, hid = r % N, kb = hid / UW, ab = (gate * UW + hid % UW) >> 2;
+            const int NS = N >= 512 ? N / 512 : 1, NPW = N / (64 * NS), ws = out >> 6;
+            const size_t idx = ((((size_t)kb * NPW + ws / NS) * NS + ws % NS) * UW + ab) * 64 + (out & 63);
+            auto b16 = [](float v) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v); };
+            fold.u6b[idx] = uint2{b16(p.x) | (b16(p.y) << 16), b16(p.z) | (b16(p.w) << 16)};
+        }
         if ((Ufwd != nullptr || Ufwd4 != nullptr) && i >= u_off4 && i < u_off4 + u_n4) {
             const size_t e = i - u_off4;        // float4 index inside U: rows 4*(e % N) .. +3 of column e / N
             const int r = 4 * (int)(e % N), k = (int)(e / N);
@@ -1038,11 +1062,12 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *_
 }
 void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
              hipStream_t st, float4 *Ubwd4, float4 *Ufwd4, const float *gpart, int n_groups, size_t group_stride, size_t by_off,
-             const float *slabs, int n_slabs, size_t slab_stride, int half_forms) {
+             const float *slabs, int n_slabs, size_t slab_stride, int half_forms, void *u6b, int u6_uw,
+             unsigned short *why_b, unsigned short *whyT_b, size_t why_off) {
     const size_t n4 = n / 4; // the flat block is a multiple of 4 floats (M = 256, N % 16 == 0)
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    const GradFold fold{gpart, n_groups, group_stride, by_off / 4, slabs, n_slabs, slab_stride};
+    const GradFold fold{gpart, n_groups, group_stride, by_off / 4, slabs, n_slabs, slab_stride, reinterpret_cast<uint2 *>(u6b), u6_uw, why_b, whyT_b, why_off / 4, (size_t)256 * N / 4};
     if (gpart != nullptr)
         hipLaunchKernelGGL(k_adagrad<true>, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4,
                            Ufwd4, fold, half_forms);

@@ -107,6 +107,7 @@ struct lstm_hip_ctx {
     bool bwd_scatter16 = false;                   // bf16 backward recurrence in its scatter form (k_bwd_scatter_bf16)
     void *Ufwd6b = nullptr, *Hxb = nullptr;       // two-half bf16 forward form: weights image, bf16 hand-off ring
     bool fwd_halves16 = false;
+    bool packed6b = false;                        // Ubwd6b is current (written by the Adagrad launch)
     // bf16 operands of the four time-batched products, k contiguous (kernels.h, gemm_bf16): Why^T and Why; per window
     // h^T [N][SBpad], dy^T [256][Tpad], dg^T [4N][Tpad] and dy [T][256]
     unsigned short *WhyT_b = nullptr, *Why_b = nullptr, *Ht_b = nullptr, *dYt_b = nullptr, *DGt_b = nullptr, *dYb = nullptr;
@@ -271,7 +272,7 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
         if (!h->packed16) {
             // (the one-recurrence forms' images only where one of them runs)
             RUN(K_PACK_U, (h->fwd_halves16 && h->bwd_scatter16 ? (void)0 : pack_U_bf16(h->P + h->pl.U, h->Ufwd16, h->Ubwd16, N, h->st),
-                           h->bwd_scatter16 ? pack_U6_bf16(h->P + h->pl.U, h->Ubwd6b, N, h->st) : (void)0,
+                           h->bwd_scatter16 && !h->packed6b ? pack_U6_bf16(h->P + h->pl.U, h->Ubwd6b, N, h->st) : (void)0,
                            h->fwd_halves16 ? pack_Ufwd6_bf16(h->P + h->pl.U, h->Ufwd6b, N, h->st) : (void)0));
             h->packed16 = true;
         }
@@ -378,7 +379,8 @@ int do_backward(lstm_hip_ctx *h) {
     // (Not for the bf16 scatter form, although its pinned launch leaves most of the chip idle -- configs[4]: 64 of 256 CUs.
     // Measured, kernel trace: of the side stream's launches only the one-workgroup column sort ran beside the recurrence; the
     // next one started and then sat until the recurrence ended, because its workgroups are dealt to the XCDs in turn and the
-    // two XCDs the recurrence fills have no room for the ones they are dealt.  Window 0.6993 -> 0.6955 ms: dropped.)
+    // two XCDs the recurrence fills have no room for the ones they are dealt.  Window 0.6993 -> 0.6955 ms: dropped.  The
+    // sort alone, queued beside the FORWARD recurrence: 0.7094 against 0.7094.)
     if (side) {
         HIP_TRY(hipEventRecord(h->ev_fork, h->st));
         HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
@@ -551,13 +553,18 @@ int do_adagrad(lstm_hip_ctx *h, double lr) {
                                h->pl.by, h->n_slabs_dU > 0 ? h->slabs_dU : nullptr, h->n_slabs_dU,
                                (size_t)4 * h->cfg.N * h->cfg.N, h->half_forms()));
     } else if (h->bf16) // the fp32 fragment images are not used by the bf16 path (its own are repacked by pack_U_bf16)
-        RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, nullptr, nullptr, h->st));
+    {   // ... except the scatter-form backward image, whose 8-byte elements are the four rows an Adagrad thread holds
+        RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, nullptr, nullptr, h->st, nullptr, nullptr,
+                               nullptr, 0, 0, 0, nullptr, 0, 0, 0, h->bwd_scatter16 ? h->Ubwd6b : nullptr,
+                               bwd_scatter_bf16_units(h->cfg.N), h->Why_b, h->WhyT_b, h->pl.Why));
+        h->packed6b = h->bwd_scatter16;
+    }
     else
     RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
                            h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, nullptr, 0, 0, 0, nullptr, 0, 0, h->half_forms()));
     h->packed = true; // the fp32 U images were refreshed by the same launch (the bf16 path has none)
     h->packed16 = false;
-    h->why_packed = false;
+    h->why_packed = h->bf16; // (the bf16 path's Adagrad launch has just rewritten both bf16 copies of Why)
     return 0;
 }
 
@@ -790,7 +797,7 @@ int lstm_hip_set_params(lstm_hip_t *h, int which, const float *host_block) {
     if (!dst || !host_block) return fail(LSTM_HIP_EINVAL, "set_params: bad block id %d or null pointer", which);
     HIP_TRY(hipMemcpyAsync(dst, host_block, sizeof(float) * h->pl.total, hipMemcpyHostToDevice, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
-    if (which == 0) h->packed = h->packed16 = h->why_packed = false;
+    if (which == 0) h->packed = h->packed16 = h->packed6b = h->why_packed = false;
     return 0;
 }
 int lstm_hip_get_params(lstm_hip_t *h, int which, float *host_block) {

@@ -1327,8 +1327,7 @@ __global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int NG = p.NG;
     int kb, g;
-    const int dbg = p.pinned >> 8; // timing experiments (LSTM_HIP_FWDHB_CFG)
-    if (p.pinned & 1) { // 8 * NB workgroups launched, workgroup i on XCD i % 8: group g = the workgroups of XCD g
+    if (p.pinned) { // 8 * NB workgroups launched, workgroup i on XCD i % 8: group g = the workgroups of XCD g
         g = (int)blockIdx.x & 7, kb = (int)blockIdx.x >> 3;
         if (g >= NG) return;
     } else {
@@ -1435,7 +1434,6 @@ __global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf
                 f32x4 acc[NSET][2];
 #pragma unroll
                 for (int sx = 0; sx < NSET; sx++) acc[sx][0] = acc[sx][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (!(dbg & 1))
 #pragma unroll
                 for (int r = 0; r < NRK; r++) {
                     const fbf16x4_t av = __builtin_bit_cast(fbf16x4_t, bv[r]);
@@ -1485,7 +1483,7 @@ __global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf
         for (int t = 1; t < S; t++) {
 #pragma unroll
             for (int gt = 0; gt < 4; gt++) wx[gt] = 0.f;
-            if (xnext >= 0 && !(dbg & 4)) {
+            if (xnext >= 0) {
 #pragma unroll
                 for (int gt = 0; gt < 4; gt++) wx[gt] = p.W[(size_t)xnext * G4 + gt * N + j]; // R/lstm.cc:176 with a one-hot x
             }
@@ -1555,10 +1553,10 @@ __global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf
                     __builtin_amdgcn_raw_buffer_store_b64(sent, rX, (int)(e_rst * sizeof(unsigned short)), 0, 16);
                 }
                 // off the chain: the plain copies the time-batched products read (fp32 H, bf16 Hb)
-                if (!(dbg & 2)) *reinterpret_cast<u32x2_t *>(p.Hb + ((size_t)t * B + col) * N + j) = u32x2_t{pack_bf16x2(h4.x, h4.y), pack_bf16x2(h4.z, h4.w)};
-                if (!(dbg & 2)) *reinterpret_cast<float4 *>(p.H + ((size_t)t * B + col) * N + j) = h4;
+                *reinterpret_cast<u32x2_t *>(p.Hb + ((size_t)t * B + col) * N + j) = u32x2_t{pack_bf16x2(h4.x, h4.y), pack_bf16x2(h4.z, h4.w)};
+                *reinterpret_cast<float4 *>(p.H + ((size_t)t * B + col) * N + j) = h4;
             }
-            if (col < B && !(dbg & 2)) {
+            if (col < B) {
                 float *gcp = p.G + ((size_t)t * B + col) * G4 + j;
                 gcp[0] = ig;
                 gcp[N] = og;
@@ -2265,7 +2263,7 @@ struct BwdsbArgs {
     float *Qx;
     unsigned *cnt, *abortp;
     unsigned epoch;
-    int ring_base, S, B, NG, pinned, cfg;
+    int ring_base, S, B, NG, pinned;
     unsigned long long *stamps;
 };
 // UW = units per workgroup: 16, or 32 where a group of N/16 workgroups would not fit one XCD (hidden 1024: 32 workgroups of
@@ -2395,10 +2393,8 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
     c1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[r], __builtin_bit_cast(bf16x4_t, a[sx][r][ab + 1]), c1, 4, ab + 1, 0);    \
     c2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[r], __builtin_bit_cast(bf16x4_t, a[sx][r][ab + 2]), c2, 4, ab + 2, 0);    \
     c3 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[r], __builtin_bit_cast(bf16x4_t, a[sx][r][ab + 3]), c3, 4, ab + 3, 0);
-                    if (!(p.cfg & 1)) {
 #pragma unroll
-                        for (int r = 0; r < NR; r++) { SB4(r, 0) SB4(r, 4) SB4(r, 8) SB4(r, 12) }
-                    }
+                    for (int r = 0; r < NR; r++) { SB4(r, 0) SB4(r, 4) SB4(r, 8) SB4(r, 12) }
 #undef SB4
                     if (sx == NS - 1) {
                         if (hf == 0) { HSTAMPQ(10) } else { HSTAMPQ(6) }
@@ -2454,17 +2450,7 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
                 const int off = (int)((((((slot * NG + g) * 2 + hf) * NB + kb) * NB + (size_t)(l >> 4)) * KK + (size_t)(16 * uh + (l & 15)) * 4) * sizeof(float));
                 float4 v[NLD];
                 bool ok = false;
-                if (p.cfg & 16) { // hint: one 16-byte piece of one source, one lane, until it flips
-                    const int hsrc = (kb + 1) % NB;
-                    const int hoff = (int)((((((slot * NG + g) * 2 + hf) * NB + kb) * NB + (size_t)hsrc) * KK + (size_t)(16 * uh) * 4) * sizeof(float));
-                    const float pv = __uint_as_float(phase);
-                    for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
-                        float4 hv = {pv, pv, pv, pv};
-                        if (l == 0) hv = ld_sc1(rQ, hoff);
-                        if (__all(bwdsb_ready(hv, phase))) break;
-                        if ((spins & 255) == 255 && __hip_atomic_load(p.abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                    }
-                }
+                // (A one-lane hint poll ahead of this loop, or pauses between the polls: 275 -> 270-272 us at hidden 1024, nothing at 512.)
                 for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
                     bool gd = true;
 #pragma unroll
@@ -2476,7 +2462,6 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
                         break;
                     }
                     if ((spins & 255) == 255 && __hip_atomic_load(p.abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                    for (int i = 0; i < ((p.cfg >> 5) & 7); i++) __builtin_amdgcn_s_sleep(1);
                 }
                 if (!ok) {
                     give_up();
@@ -2554,12 +2539,12 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
                     t3 = r1;
                 }
             }
-            if (ecol < B && !(p.cfg & 4)) {
+            if (ecol < B) {
                 const float4 v = {t0, t1, t2, t3};
                 *reinterpret_cast<float4 *>(p.DG + ((size_t)t * B + ecol) * G4 + ta * N + UW * kb + 16 * uh + 4 * tq) = v;
             }
             HSTAMPQ(4)
-            if (t >= 2 && !(p.cfg & 8)) fetch(t - 1);
+            if (t >= 2) fetch(t - 1);
         }
     }
 #undef HSTAMPQ
@@ -3318,9 +3303,8 @@ void fwd_halves_bf16(const void *Ufwd6b, const float *W, const float *bias, floa
                      int B, bool fast, int n_cus, hipStream_t st, unsigned long long *stamps) {
     const int NB = N / fwd_halves_bf16_units(N), NG = (B + 7) / 8;
     static const bool no_pin = getenv("LSTM_HIP_NO_PIN") && atoi(getenv("LSTM_HIP_NO_PIN")); // A/B
-    static const int dbg = getenv("LSTM_HIP_FWDHB_CFG") ? atoi(getenv("LSTM_HIP_FWDHB_CFG")) : 0; // timing experiments only
-    const int pinned = (NG < 8 && 8 * NB <= n_cus && !no_pin ? 1 : 0) | (dbg << 8);
-    const dim3 grid((pinned & 1) ? 8 * NB : NB * NG);
+    const int pinned = NG < 8 && 8 * NB <= n_cus && !no_pin;
+    const dim3 grid(pinned ? 8 * NB : NB * NG);
     const FwdhbArgs args = {reinterpret_cast<const uint2 *>(Ufwd6b), W, bias, H, Hb, C, G, xi, reinterpret_cast<unsigned *>(Hxb), cnt, abortp,
                             epoch, ring_base, S, B, NG, pinned, stamps};
 #define GO(n, u)                                                                                                               \
@@ -3457,9 +3441,8 @@ void bwd_scatter_bf16(const void *Ubwd6b, float *DG, const float *DHy, const flo
     const int NB = N / bwd_scatter_bf16_units(N), NG = (B + 7) / 8;
     static const int spread = getenv("LSTM_HIP_BWD_SPREAD") && atoi(getenv("LSTM_HIP_BWD_SPREAD")) ? 1 : 0;
     const int pinned = bwdsb_pinned(N, B, n_cus) && !spread;
-    static const int cfg = getenv("LSTM_HIP_BWDSB_CFG") ? atoi(getenv("LSTM_HIP_BWDSB_CFG")) : 0; // timing experiments only
     const dim3 grid(pinned ? 8 * NB : NB * NG);
-    const BwdsbArgs args = {reinterpret_cast<const uint2 *>(Ubwd6b), DG, DHy, G, C, Qx, cnt, abortp, epoch, ring_base, S, B, NG, pinned, cfg, stamps};
+    const BwdsbArgs args = {reinterpret_cast<const uint2 *>(Ubwd6b), DG, DHy, G, C, Qx, cnt, abortp, epoch, ring_base, S, B, NG, pinned, stamps};
     if (N == 1024 && stamps) hipLaunchKernelGGL((k_bwd_scatter_bf16<1024, 32, true>), grid, dim3(BwdsbShape<1024, 32>::THREADS), 0, st, args);
     else if (N == 1024) hipLaunchKernelGGL((k_bwd_scatter_bf16<1024, 32>), grid, dim3(BwdsbShape<1024, 32>::THREADS), 0, st, args);
     else if (N == 512 && stamps) hipLaunchKernelGGL((k_bwd_scatter_bf16<512, 16, true>), grid, dim3(BwdsbShape<512, 16>::THREADS), 0, st, args);
