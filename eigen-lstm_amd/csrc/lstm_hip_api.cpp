@@ -276,10 +276,15 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
                            h->fwd_halves16 ? pack_Ufwd6_bf16(h->P + h->pl.U, h->Ufwd6b, N, h->st) : (void)0));
             h->packed16 = true;
         }
-        if (h->fwd_halves16) {
-            RUN(K_FWD_PERSIST, fwd_halves_bf16(h->Ufwd6b, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi, h->Hxb,
-                                               h->cnt, h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->n_cus, h->st, h->stamps));
-            h->ring_base = fwd_ring_advance(h->ring_base, S);
+        if (h->fwd_halves16) { // as many 8-column groups per launch as are co-resident; the streams are independent
+            const int lc = fwd_halves_bf16_launch_cols(N, h->n_cus);
+            for (int c0 = 0; c0 < B; c0 += lc) {
+                if (c0 > 0) h->fwd_epoch++;
+                RUN(K_FWD_PERSIST, fwd_halves_bf16(h->Ufwd6b, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi, h->Hxb,
+                                                   h->cnt, h->abortp, h->fwd_epoch, h->ring_base, N, S, B, c0, B - c0 < lc ? B - c0 : lc,
+                                                   fast, h->n_cus, h->st, h->stamps));
+            }
+            h->ring_base = fwd_ring_advance(h->ring_base, S); // (every column range has made the same S - 1 hand-offs on its part of the ring)
             return 0;
         }
         RUN(K_FWD_PERSIST, fwd_persistent_bf16(h->Ufwd16, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi,
@@ -395,9 +400,14 @@ int do_backward(lstm_hip_ctx *h) {
         }
         h->bwd_epoch++;
         if (h->bf16 && h->bwd_scatter16) {
-            RUN(K_BWD_PERSIST, bwd_scatter_bf16(h->Ubwd6b, h->DG, h->DHy, h->G, h->C, h->DGx, cb, h->abortp, h->bwd_epoch,
-                                                h->ring_base_b, N, S, B, h->n_cus, h->st, h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr));
-            h->ring_base_b = bwd_scatter_bf16_ring_advance(h->ring_base_b, S);
+            const int lc = bwd_scatter_bf16_launch_cols(N, h->n_cus); // one launch per co-resident range of columns
+            for (int c0 = 0; c0 < B; c0 += lc) {
+                if (c0 > 0) h->bwd_epoch++;
+                RUN(K_BWD_PERSIST, bwd_scatter_bf16(h->Ubwd6b, h->DG, h->DHy, h->G, h->C, h->DGx, cb, h->abortp, h->bwd_epoch,
+                                                    h->ring_base_b, N, S, B, c0, B - c0 < lc ? B - c0 : lc, h->n_cus, h->st,
+                                                    h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr));
+            }
+            h->ring_base_b = bwd_scatter_bf16_ring_advance(h->ring_base_b, S); // (every group's region has had its S - 2 publications)
         } else if (h->bf16) {
             RUN(K_BWD_PERSIST, bwd_persistent(reinterpret_cast<const float4 *>(h->Ubwd16), h->DG, h->DHy, h->G, h->C, h->H,
                                               h->xi, fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp,
@@ -721,7 +731,7 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
         }
         if (h->bwd_scatter16) {
             HIP_TRY(hipMalloc(&h->Ubwd6b, (size_t)8 * N * N));
-            h->DGx_floats = bwd_scatter_bf16_ring_floats((int)N, (int)B);
+            h->DGx_floats = bwd_scatter_bf16_ring_floats((int)N, (int)B, prop.multiProcessorCount);
             ALLOC(h->DGx, h->DGx_floats);
             HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * h->DGx_floats));
         }

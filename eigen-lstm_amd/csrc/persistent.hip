@@ -1311,7 +1311,7 @@ struct FwdhbArgs {
     unsigned *Hxb; // ring, as 32-bit words (two bf16 each)
     unsigned *cnt, *abortp;
     unsigned epoch;
-    int ring_base, S, B, NG, pinned;
+    int ring_base, S, B, NG, pinned, col0; // columns col0 .. col0 + 8*NG - 1 of the B (a launch takes as many groups as are co-resident)
     unsigned long long *stamps;
 };
 __device__ __forceinline__ bool hxb_ready(const u32x2_t &v) { return v.x != HX_SENT && v.y != HX_SENT; }
@@ -1377,7 +1377,7 @@ __global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf
         int colv[2];
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            const int c = 8 * g + 4 * hf + li;
+            const int c = p.col0 + 8 * g + 4 * hf + li;
             colv[hf] = c < B ? c : B - 1;
         }
         // h_0 of both halves (plain fp32 window state in H, rounded here); later fragments come from the ring
@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf
         const int hf = (w - 8) / NEH, uh = (w - 8) % NEH;
         __builtin_amdgcn_s_setprio(3);
         const int gc = l >> 4, gu = l & 15;
-        const int col = 8 * g + 4 * hf + gc, colc = col < B ? col : B - 1;
+        const int col = p.col0 + 8 * g + 4 * hf + gc, colc = col < B ? col : B - 1;
         const int j = UW * kb + 16 * uh + gu;
         float bs[4], cprev, wx[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -2263,7 +2263,7 @@ struct BwdsbArgs {
     float *Qx;
     unsigned *cnt, *abortp;
     unsigned epoch;
-    int ring_base, S, B, NG, pinned;
+    int ring_base, S, B, NG, pinned, col0; // columns col0 .. col0 + 8*NG - 1 of the B
     unsigned long long *stamps;
 };
 // UW = units per workgroup: 16, or 32 where a group of N/16 workgroups would not fit one XCD (hidden 1024: 32 workgroups of
@@ -2317,6 +2317,9 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
     // diagnostics (LSTM_HIP_DEBUG_STAMPS): lane 0 of waves 3 and 8 of workgroups (0, 0) and (NB/2, 0); slots as in k_bwd_scatter
     unsigned long long *stq = STAMP && g == 0 && (kb == 0 || kb == NB / 2) && l == 0 && (w == 3 || w == 8) ? p.stamps + (size_t)(kb ? 1 : 0) * S * 16 : nullptr;
 #define HSTAMPQ(k) if (STAMP && stq) stq[(size_t)t * 16 + (k)] = __builtin_amdgcn_s_memtime();
+    // the ring has a region per group of the WHOLE batch (gg): a region is written once per window, by the launch that owns its
+    // columns, so every region sees the same sequence of slots and phases whatever the batch is split into
+    const int NGT = (B + 7) / 8, gg = p.col0 / 8 + g;
     const __amdgpu_buffer_rsrc_t rQ = make_rsrc(Qx, bwdsb_ring_floats(N, UW, B) * sizeof(float));
     unsigned *xcc_tab = p.cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
     if (tid == 0) {
@@ -2407,8 +2410,8 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
                     const float sv = __uint_as_float(HX_SENT);
                     const float4 sent = {sv, sv, sv, sv};
                     const int out = (w * NS + sx) * 64 + l, d = out / UW, u = out % UW;
-                    const int e_pub = ((((spub * NG + g) * 2 + hf) * NB + d) * NB + kb) * KK + u * 4;
-                    const int e_rst = ((((srst * NG + g) * 2 + hf) * NB + d) * NB + kb) * KK + u * 4;
+                    const int e_pub = ((((spub * NGT + gg) * 2 + hf) * NB + d) * NB + kb) * KK + u * 4;
+                    const int e_rst = ((((srst * NGT + gg) * 2 + hf) * NB + d) * NB + kb) * KK + u * 4;
                     if (XCD_LOCAL && local) {
                         *reinterpret_cast<float4 *>(Qx + e_pub) = q;
                         if (!BWDSB_TAGGED) *reinterpret_cast<float4 *>(Qx + e_rst) = sent;
@@ -2427,7 +2430,7 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
         const int hf = (w - 8) / NEH, uh = (w - 8) % NEH;
         __builtin_amdgcn_s_setprio(3);
         const int cc = l >> 4, jj = l & 15;
-        const int ecol = 8 * g + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
+        const int ecol = p.col0 + 8 * g + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
         const int uu = 16 * uh + jj, j = UW * kb + uu;
         float dcn = 0.0f; // dcnext, R/lstm.cc:217
         bool local_pub = false;
@@ -2447,7 +2450,7 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
                 const int seq = ring_base + (S - 2 - t); // publication number of Q_{t+1}
                 const size_t slot = (size_t)(seq & (HX_RING - 1));
                 const unsigned phase = (unsigned)(seq >> 2) & 1u;
-                const int off = (int)((((((slot * NG + g) * 2 + hf) * NB + kb) * NB + (size_t)(l >> 4)) * KK + (size_t)(16 * uh + (l & 15)) * 4) * sizeof(float));
+                const int off = (int)((((((slot * NGT + gg) * 2 + hf) * NB + kb) * NB + (size_t)(l >> 4)) * KK + (size_t)(16 * uh + (l & 15)) * 4) * sizeof(float));
                 float4 v[NLD];
                 bool ok = false;
                 // (A one-lane hint poll ahead of this loop, or pauses between the polls: 275 -> 270-272 us at hidden 1024, nothing at 512.)
@@ -3284,10 +3287,13 @@ size_t fwd_halves_bf16_ring_halfwords(int N, int B) { return (size_t)HX_RING * N
         else if (N == 512) GO(512, 16);   \
         else GO(256, 16);                 \
     } while (0)
+// columns one launch takes: as many 8-column groups as are co-resident, one workgroup per CU (a wider batch runs as several
+// launches over column ranges -- the streams are independent recurrences)
+int fwd_halves_bf16_launch_cols(int N, int n_cus) { return 8 * (n_cus / (N / fwd_halves_bf16_units(N))); }
 bool fwd_halves_bf16_supported(int N, int B, int n_cus) {
     if (N != 256 && N != 512 && N != 1024) return false;
     if (B % 4 != 0) return false; // 8-byte ring pieces and Hb rows
-    const size_t grid = (size_t)(N / fwd_halves_bf16_units(N)) * ((B + 7) / 8);
+    if (fwd_halves_bf16_launch_cols(N, n_cus) < 8) return false;
     int per_cu = 0;
 #define GO(n, u)                                                                                                                  \
     per_cu = blocks_per_cu(k_fwd_halves_bf16<n, u, false>, FwdhbShape<n, u>::THREADS, FwdhbShape<n, u>::LDS) > 0 &&               \
@@ -3296,17 +3302,18 @@ bool fwd_halves_bf16_supported(int N, int B, int n_cus) {
                  : 0
     FHB_DISPATCH(GO);
 #undef GO
-    return per_cu >= 1 && grid <= (size_t)n_cus;
+    return per_cu >= 1;
 }
+// one launch: columns [col0, col0 + cols) of the B, cols <= fwd_halves_bf16_launch_cols; ring_base is that column range's own
 void fwd_halves_bf16(const void *Ufwd6b, const float *W, const float *bias, float *H, unsigned short *Hb, float *C, float *G,
                      const int32_t *xi, void *Hxb, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S,
-                     int B, bool fast, int n_cus, hipStream_t st, unsigned long long *stamps) {
-    const int NB = N / fwd_halves_bf16_units(N), NG = (B + 7) / 8;
+                     int B, int col0, int cols, bool fast, int n_cus, hipStream_t st, unsigned long long *stamps) {
+    const int NB = N / fwd_halves_bf16_units(N), NG = (cols + 7) / 8;
     static const bool no_pin = getenv("LSTM_HIP_NO_PIN") && atoi(getenv("LSTM_HIP_NO_PIN")); // A/B
     const int pinned = NG < 8 && 8 * NB <= n_cus && !no_pin;
     const dim3 grid(pinned ? 8 * NB : NB * NG);
     const FwdhbArgs args = {reinterpret_cast<const uint2 *>(Ufwd6b), W, bias, H, Hb, C, G, xi, reinterpret_cast<unsigned *>(Hxb), cnt, abortp,
-                            epoch, ring_base, S, B, NG, pinned, stamps};
+                            epoch, ring_base, S, B, NG, pinned, col0, stamps};
 #define GO(n, u)                                                                                                               \
     do {                                                                                                                       \
         if (stamps) hipLaunchKernelGGL((k_fwd_halves_bf16<n, u, false, true>), grid, dim3(FwdhbShape<n, u>::THREADS), (FwdhbShape<n, u>::LDS), st, args); \
@@ -3421,28 +3428,30 @@ void bwd_scatter(const float4 *Ubwd6, float *DG, const float *Why, const float *
 int bwd_scatter_bf16_units(int N) { return N == 1024 ? 32 : 16; }
 // publication number of the next launch's first hand-off (slot = low two bits, parity = bit 2)
 int bwd_scatter_bf16_ring_advance(int base, int S) { return (base + (S > 2 ? S - 2 : 0)) & 7; }
-static bool bwdsb_pinned(int N, int B, int n_cus) {
-    const int NB = N / bwd_scatter_bf16_units(N), NG = (B + 7) / 8;
-    return NG < 8 && 8 * NB <= n_cus;
+int bwd_scatter_bf16_launch_cols(int N, int n_cus) { return 8 * (n_cus / (N / bwd_scatter_bf16_units(N))); }
+size_t bwd_scatter_bf16_ring_floats(int N, int B, int n_cus) {
+    (void)n_cus;
+    return bwdsb_ring_floats(N, bwd_scatter_bf16_units(N), B); // a region per column group of the whole batch
 }
-size_t bwd_scatter_bf16_ring_floats(int N, int B) { return bwdsb_ring_floats(N, bwd_scatter_bf16_units(N), B); }
 bool bwd_scatter_bf16_supported(int N, int B, int n_cus) {
     if (N != 256 && N != 512 && N != 1024) return false;
-    const size_t grid = (size_t)(N / bwd_scatter_bf16_units(N)) * ((B + 7) / 8);
+    (void)B;
+    if (bwd_scatter_bf16_launch_cols(N, n_cus) < 8) return false;
     int per_cu = 0;
     if (N == 1024) per_cu = blocks_per_cu(k_bwd_scatter_bf16<1024, 32>, BwdsbShape<1024, 32>::THREADS);
     else if (N == 512) per_cu = blocks_per_cu(k_bwd_scatter_bf16<512, 16>, BwdsbShape<512, 16>::THREADS);
     else per_cu = blocks_per_cu(k_bwd_scatter_bf16<256, 16>, BwdsbShape<256, 16>::THREADS);
-    return per_cu >= 1 && grid <= (size_t)n_cus;
+    return per_cu >= 1;
 }
+// one launch: columns [col0, col0 + cols) of the B, cols <= bwd_scatter_bf16_launch_cols
 void bwd_scatter_bf16(const void *Ubwd6b, float *DG, const float *DHy, const float *G, const float *C, float *Qx, unsigned *cnt,
-                      unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int n_cus, hipStream_t st,
+                      unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int col0, int cols, int n_cus, hipStream_t st,
                       unsigned long long *stamps) {
-    const int NB = N / bwd_scatter_bf16_units(N), NG = (B + 7) / 8;
+    const int NB = N / bwd_scatter_bf16_units(N), NG = (cols + 7) / 8;
     static const int spread = getenv("LSTM_HIP_BWD_SPREAD") && atoi(getenv("LSTM_HIP_BWD_SPREAD")) ? 1 : 0;
-    const int pinned = bwdsb_pinned(N, B, n_cus) && !spread;
+    const int pinned = NG < 8 && 8 * NB <= n_cus && !spread;
     const dim3 grid(pinned ? 8 * NB : NB * NG);
-    const BwdsbArgs args = {reinterpret_cast<const uint2 *>(Ubwd6b), DG, DHy, G, C, Qx, cnt, abortp, epoch, ring_base, S, B, NG, pinned, stamps};
+    const BwdsbArgs args = {reinterpret_cast<const uint2 *>(Ubwd6b), DG, DHy, G, C, Qx, cnt, abortp, epoch, ring_base, S, B, NG, pinned, col0, stamps};
     if (N == 1024 && stamps) hipLaunchKernelGGL((k_bwd_scatter_bf16<1024, 32, true>), grid, dim3(BwdsbShape<1024, 32>::THREADS), 0, st, args);
     else if (N == 1024) hipLaunchKernelGGL((k_bwd_scatter_bf16<1024, 32>), grid, dim3(BwdsbShape<1024, 32>::THREADS), 0, st, args);
     else if (N == 512 && stamps) hipLaunchKernelGGL((k_bwd_scatter_bf16<512, 16, true>), grid, dim3(BwdsbShape<512, 16>::THREADS), 0, st, args);

@@ -43,6 +43,7 @@ def test_two_handles_same_seed_bit_identical(N, S, B, windows):
     (1024, 100, 16, 1500),  # BASELINE configs[4]: 32 units to a workgroup, two groups pinned to two XCDs
     (512, 25, 64, 3000),    # eight groups, eight XCDs; odd number of hand-offs per launch (slot and phase walk)
     (1024, 9, 64, 1000),    # hidden 1024, 64 streams: every CU holds a workgroup
+    (512, 11, 96, 1000),    # two launches per direction (64 + 32 columns) sharing the backward ring
 ])
 def test_bf16_forms_two_handles_bit_identical(N, S, B, windows):
     """The bf16 recurrences (k_fwd_halves_bf16, k_bwd_scatter_bf16): sentinel ring forward, phase-tagged ring backward."""

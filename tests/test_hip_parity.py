@@ -784,9 +784,10 @@ def test_create_destroy_does_not_leak():
 
 
 # (256, 9, 72): 9 column groups, the unpinned placement; (512, 7, 16) / (1024, ...): fewer than 8 groups, one group pinned to
-# each XCD; (1024, 5, 64): hidden 1024 with 8 groups of 32 workgroups -- the whole chip, one workgroup per CU
+# each XCD; (1024, 5, 64): hidden 1024 with 8 groups of 32 workgroups -- the whole chip, one workgroup per CU; (1024, 4, 128)
+# and (512, 6, 88): wider than that, two launches per direction over column ranges (64 + 64, 64 + 24)
 @pytest.mark.parametrize("N,S,B", [(128, 6, 8), (256, 10, 24), (256, 9, 72), (512, 12, 64), (512, 7, 16), (1024, 4, 16),
-                                   (1024, 5, 64)])
+                                   (1024, 5, 64), (1024, 4, 128), (512, 6, 88)])
 def test_bf16_recurrence_matches_bf16_oracle(N, S, B, oracle32):
     """LSTM_HIP_BF16_RECURRENCE (BASELINE configs[4] semantics: bf16 MFMA operands in the two recurrent and the four
     time-batched products, fp32 accumulate and fp32 everything else) against the oracle in the same mode (those operands
@@ -882,13 +883,14 @@ def test_bf16_flag_is_refused_where_unsupported(oracle32):
     import lstm_hip
     with pytest.raises(lstm_hip.LstmHipError):
         lstm_hip.Lstm(64, 5, 8, flags=lstm_hip.BF16_RECURRENCE)   # N not a multiple of 128
-    # the persistent grids must be co-resident: hidden 1024 with 128 streams needs 1024 forward workgroups of 512 threads
-    # (four to a CU) -- refused at create, before any allocation, with the reason ...
+    # the persistent grids must be co-resident: hidden 896 (one-recurrence forms only) with 512 streams needs 7168 forward
+    # workgroups -- refused at create, before any allocation, with the reason ...
     with pytest.raises(lstm_hip.LstmHipError, match="co-resident"):
-        lstm_hip.Lstm(1024, 5, 128, flags=lstm_hip.BF16_RECURRENCE)
+        lstm_hip.Lstm(896, 5, 512, flags=lstm_hip.BF16_RECURRENCE)
     with pytest.raises(lstm_hip.LstmHipError, match="multiple of 8"):
         lstm_hip.Lstm(256, 5, 20, flags=lstm_hip.BF16_RECURRENCE)  # bf16 operand rows must stay 16-byte aligned
-    # ... while a batch whose 8-column groups do not fit (16 * 17 = 272 > 256 CUs) runs on 16-column groups (16 * 9)
+    # ... while hidden 256 / 512 / 1024 take any batch: the two-half forms run a batch wider than the chip holds at one
+    # workgroup per CU as several launches over column ranges (here 128 + 8 columns)
     N, S, B = 256, 5, 136
     P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=5, scale=0.05)
     oracle32.set_bf16_recurrence(True)

@@ -13,7 +13,7 @@ import json
 import sys
 from collections import defaultdict
 
-NAMES = {"k_bwd_persistent": "bwd_persistent", "k_bwd_scatter": "bwd_persistent", "k_fwd_persistent": "fwd_persistent",
+NAMES = {"k_bwd_persistent": "bwd_persistent", "k_bwd_scatter": "bwd_persistent", "k_fwd_persistent": "fwd_persistent", "k_fwd_halves_bf16": "fwd_persistent",
          "k_gemm_regs<false, false": "gemm_dU", "k_gemm_regs<false, true": "gemm_Y"}
 OUT = sys.argv[2] if len(sys.argv) > 2 else "profiles/r3_mfma_util.json"
 acc = defaultdict(lambda: defaultdict(list))

@@ -14,7 +14,7 @@ import os
 import sys
 from collections import defaultdict
 
-NAMES = {"k_bwd_persistent": "bwd_persistent", "k_bwd_scatter": "bwd_persistent", "k_fwd_persistent": "fwd_persistent",
+NAMES = {"k_bwd_persistent": "bwd_persistent", "k_bwd_scatter": "bwd_persistent", "k_fwd_persistent": "fwd_persistent", "k_fwd_halves_bf16": "fwd_persistent",
          "k_gemm_regs<false, false": "gemm_dU", "k_gemm_regs<false, true": "gemm_Y", "k_gemm_regs<true, true": "gemm_DHy",
          "k_gemm_bf16": "gemm_bf16", "k_adagrad": "adagrad", "k_softmax_loss_dy": "softmax_loss_dy"}
 

@@ -1,6 +1,6 @@
 """Soak: two handles, same seed and text, W windows each at the headline shape; the parameters must come out bit-identical
 (every kernel of the path is deterministic, so a difference would mean a race in a hand-off).
-  python tools/soak_determinism.py [windows [N S B]]"""
+  python tools/soak_determinism.py [windows [N S B [flags]]]      (flags 128: the bf16 recurrences)"""
 import os
 import sys
 
@@ -14,10 +14,11 @@ from bench import synthetic_text  # noqa: E402
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 12000
 N, S, B = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (512, 100, 64)
+FLAGS = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 text = synthetic_text(1_000_000, seed=0)
 out = []
 for rep in range(2):
-    L = lstm_hip.Lstm(N, S, B)
+    L = lstm_hip.Lstm(N, S, B, flags=FLAGS)
     L.set_params(lstm_hip.init_params(lstm_hip.MT19937Normal(1), N))
     L.set_text(text)
     L.set_cursors(lstm_hip.initial_cursors(len(text), S, B))
