@@ -103,9 +103,9 @@ size_t fwd_halves_bf16_ring_halfwords(int N, int B);
 void fwd_halves_bf16(const void *Ufwd6b, const float *W, const float *bias, float *H, unsigned short *Hb, float *C, float *G,
                      const int32_t *xi, void *Hxb, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S,
                      int B, int col0, int cols, bool fast, int n_cus, hipStream_t st, unsigned long long *stamps);
-int fwd_halves_bf16_launch_cols(int N, int n_cus); // a launch takes this many columns; wider batches run as several launches
+int fwd_halves_bf16_launch_cols(int N, int B, int n_cus); // a launch takes this many columns; wider batches run as several launches
 size_t bwd_scatter_bf16_ring_floats(int N, int B, int n_cus);
-int bwd_scatter_bf16_launch_cols(int N, int n_cus);
+int bwd_scatter_bf16_launch_cols(int N, int B, int n_cus);
 int bwd_scatter_bf16_units(int N);
 int bwd_scatter_bf16_ring_advance(int base, int S);
 void bwd_scatter_bf16(const void *Ubwd6b, float *DG, const float *DHy, const float *G, const float *C, float *Qx, unsigned *cnt,

@@ -277,7 +277,7 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
             h->packed16 = true;
         }
         if (h->fwd_halves16) { // as many 8-column groups per launch as are co-resident; the streams are independent
-            const int lc = fwd_halves_bf16_launch_cols(N, h->n_cus);
+            const int lc = fwd_halves_bf16_launch_cols(N, B, h->n_cus);
             for (int c0 = 0; c0 < B; c0 += lc) {
                 if (c0 > 0) h->fwd_epoch++;
                 RUN(K_FWD_PERSIST, fwd_halves_bf16(h->Ufwd6b, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi, h->Hxb,
@@ -400,7 +400,7 @@ int do_backward(lstm_hip_ctx *h) {
         }
         h->bwd_epoch++;
         if (h->bf16 && h->bwd_scatter16) {
-            const int lc = bwd_scatter_bf16_launch_cols(N, h->n_cus); // one launch per co-resident range of columns
+            const int lc = bwd_scatter_bf16_launch_cols(N, B, h->n_cus); // one launch per co-resident range of columns
             for (int c0 = 0; c0 < B; c0 += lc) {
                 if (c0 > 0) h->bwd_epoch++;
                 RUN(K_BWD_PERSIST, bwd_scatter_bf16(h->Ubwd6b, h->DG, h->DHy, h->G, h->C, h->DGx, cb, h->abortp, h->bwd_epoch,

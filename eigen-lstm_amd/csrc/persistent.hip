@@ -1311,7 +1311,7 @@ struct FwdhbArgs {
     unsigned *Hxb; // ring, as 32-bit words (two bf16 each)
     unsigned *cnt, *abortp;
     unsigned epoch;
-    int ring_base, S, B, NG, pinned, col0; // columns col0 .. col0 + 8*NG - 1 of the B (a launch takes as many groups as are co-resident)
+    int ring_base, S, B, NG, pinned, col0, gcols; // columns col0 .. col0 + gcols*NG - 1 of the B (a launch takes as many groups as are co-resident)
     unsigned long long *stamps;
 };
 __device__ __forceinline__ bool hxb_ready(const u32x2_t &v) { return v.x != HX_SENT && v.y != HX_SENT; }
@@ -1325,7 +1325,7 @@ __global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf
     __shared__ int s_abort;
     __shared__ unsigned s_done[2][2];
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int NG = p.NG;
+    const int NG = p.NG, GC = p.gcols; // GC = 8: two halves of four columns per workgroup; 4: one (half B's waves leave)
     int kb, g;
     if (p.pinned) { // 8 * NB workgroups launched, workgroup i on XCD i % 8: group g = the workgroups of XCD g
         g = (int)blockIdx.x & 7, kb = (int)blockIdx.x >> 3;
@@ -1377,7 +1377,7 @@ __global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf
         int colv[2];
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            const int c = p.col0 + 8 * g + 4 * hf + li;
+            const int c = p.col0 + GC * g + 4 * hf + li;
             colv[hf] = c < B ? c : B - 1;
         }
         // h_0 of both halves (plain fp32 window state in H, rounded here); later fragments come from the ring
@@ -1395,6 +1395,7 @@ __global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf
         for (int t = 1; t < S; t++) {
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
+                if (hf == 1 && GC == 4) continue;
                 if (hf == 0) { HSTAMPQ(8) }
                 u32x2_t bv[NRK];
                 bool have = true;
@@ -1430,7 +1431,7 @@ __global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf
                 // instructions and looked at when that half is next
                 const int nslot = (t - 1 + hf + ring_base) & (HX_RING - 1);
                 const int noff = (int)((((size_t)nslot * B + colv[hf ^ 1]) * N + Kw * w + 4 * lb) * sizeof(unsigned short));
-                const bool req = hf == 0 ? t > 1 : t + 1 < S;
+                const bool req = GC == 8 && (hf == 0 ? t > 1 : t + 1 < S);
                 f32x4 acc[NSET][2];
 #pragma unroll
                 for (int sx = 0; sx < NSET; sx++) acc[sx][0] = acc[sx][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1452,6 +1453,10 @@ __global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf
                     for (int r = 0; r < NRK; r++)
                         bvq[hf ^ 1][r] = ld_lane ? __builtin_amdgcn_raw_buffer_load_b64(rX, noff + 128 * r, 0, 16) : u32x2_t{0u, 0u};
                 }
+                if (GC == 4) { // one half only: its next fragment cannot have been published yet, the poll above fetches it
+#pragma unroll
+                    for (int r = 0; r < NRK; r++) bvq[0][r] = u32x2_t{HX_SENT, HX_SENT};
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (hf == 0) { HSTAMPQ(10) } else { HSTAMPQ(6) }
                 // lane (unit u, gate j), register i = column i of the half: one row of the image per (wave, column).  No workgroup
@@ -1469,9 +1474,10 @@ __global__ __launch_bounds__((FwdhbShape<N_, UW>::THREADS)) void k_fwd_halves_bf
     } else {
         // ---------------- gating waves: NEH per half, 16 units each; lane = column*16 + unit ----------------
         const int hf = (w - 8) / NEH, uh = (w - 8) % NEH;
+        if (hf == 1 && GC == 4) return;
         __builtin_amdgcn_s_setprio(3);
         const int gc = l >> 4, gu = l & 15;
-        const int col = p.col0 + 8 * g + 4 * hf + gc, colc = col < B ? col : B - 1;
+        const int col = p.col0 + GC * g + 4 * hf + gc, colc = col < B ? col : B - 1;
         const int j = UW * kb + 16 * uh + gu;
         float bs[4], cprev, wx[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -2263,7 +2269,7 @@ struct BwdsbArgs {
     float *Qx;
     unsigned *cnt, *abortp;
     unsigned epoch;
-    int ring_base, S, B, NG, pinned, col0; // columns col0 .. col0 + 8*NG - 1 of the B
+    int ring_base, S, B, NG, pinned, col0, gcols; // columns col0 .. col0 + gcols*NG - 1 of the B
     unsigned long long *stamps;
 };
 // UW = units per workgroup: 16, or 32 where a group of N/16 workgroups would not fit one XCD (hidden 1024: 32 workgroups of
@@ -2285,6 +2291,9 @@ __host__ __device__ inline size_t bwdsb_ring_floats(int N, int UW, int B) {
 #ifndef BWDSB_TAGGED
 #define BWDSB_TAGGED 1
 #endif
+#ifndef BF16_SINGLE_HALF_DEFAULT
+#define BF16_SINGLE_HALF_DEFAULT 0
+#endif
 __device__ __forceinline__ float bwdsb_mark(float v, unsigned phase) {
     if (!BWDSB_TAGGED) return hx_canon(v);
     return __uint_as_float((__float_as_uint(v) & ~1u) | phase);
@@ -2304,7 +2313,7 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
     __shared__ unsigned s_done[2][2], s_loc[2];
     __shared__ int s_abort;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int NG = p.NG;
+    const int NG = p.NG, GC = p.gcols; // GC = 8: two halves of four columns per workgroup; 4: one (half B's waves leave)
     int kb, g;
     if (p.pinned) { // 8 * NB workgroups launched: workgroup i runs on XCD i % 8; group g lives on XCD g, the rest leave
         g = (int)blockIdx.x & 7, kb = (int)blockIdx.x >> 3;
@@ -2319,7 +2328,8 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
 #define HSTAMPQ(k) if (STAMP && stq) stq[(size_t)t * 16 + (k)] = __builtin_amdgcn_s_memtime();
     // the ring has a region per group of the WHOLE batch (gg): a region is written once per window, by the launch that owns its
     // columns, so every region sees the same sequence of slots and phases whatever the batch is split into
-    const int NGT = (B + 7) / 8, gg = p.col0 / 8 + g;
+    // (regions are counted in halves: region of (group, half) = its first column / 4)
+    const int NRG = 2 * ((B + 7) / 8), rg0 = (p.col0 + GC * g) / 4;
     const __amdgpu_buffer_rsrc_t rQ = make_rsrc(Qx, bwdsb_ring_floats(N, UW, B) * sizeof(float));
     unsigned *xcc_tab = p.cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;
     if (tid == 0) {
@@ -2372,6 +2382,7 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
         for (int t = S - 1; t >= 2; t--) {
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
+                if (hf == 1 && GC == 4) continue;
                 if (hf == 0) { HSTAMPQ(8) }
                 if (!lds_wait(&s_done[hf][t & 1], (unsigned)(NEH * ((S - 1 - t) / 2 + 1)))) {
                     give_up();
@@ -2410,8 +2421,8 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
                     const float sv = __uint_as_float(HX_SENT);
                     const float4 sent = {sv, sv, sv, sv};
                     const int out = (w * NS + sx) * 64 + l, d = out / UW, u = out % UW;
-                    const int e_pub = ((((spub * NGT + gg) * 2 + hf) * NB + d) * NB + kb) * KK + u * 4;
-                    const int e_rst = ((((srst * NGT + gg) * 2 + hf) * NB + d) * NB + kb) * KK + u * 4;
+                    const int e_pub = ((((spub * NRG + rg0 + hf)) * NB + d) * NB + kb) * KK + u * 4;
+                    const int e_rst = ((((srst * NRG + rg0 + hf)) * NB + d) * NB + kb) * KK + u * 4;
                     if (XCD_LOCAL && local) {
                         *reinterpret_cast<float4 *>(Qx + e_pub) = q;
                         if (!BWDSB_TAGGED) *reinterpret_cast<float4 *>(Qx + e_rst) = sent;
@@ -2428,9 +2439,10 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
     } else {
         // ---------------- elementwise waves: NEH per half (16 units each); lane = column*16 + unit ----------------
         const int hf = (w - 8) / NEH, uh = (w - 8) % NEH;
+        if (hf == 1 && GC == 4) return;
         __builtin_amdgcn_s_setprio(3);
         const int cc = l >> 4, jj = l & 15;
-        const int ecol = p.col0 + 8 * g + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
+        const int ecol = p.col0 + GC * g + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
         const int uu = 16 * uh + jj, j = UW * kb + uu;
         float dcn = 0.0f; // dcnext, R/lstm.cc:217
         bool local_pub = false;
@@ -2450,7 +2462,7 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
                 const int seq = ring_base + (S - 2 - t); // publication number of Q_{t+1}
                 const size_t slot = (size_t)(seq & (HX_RING - 1));
                 const unsigned phase = (unsigned)(seq >> 2) & 1u;
-                const int off = (int)((((((slot * NGT + gg) * 2 + hf) * NB + kb) * NB + (size_t)(l >> 4)) * KK + (size_t)(16 * uh + (l & 15)) * 4) * sizeof(float));
+                const int off = (int)((((((slot * NRG + rg0 + hf)) * NB + kb) * NB + (size_t)(l >> 4)) * KK + (size_t)(16 * uh + (l & 15)) * 4) * sizeof(float));
                 float4 v[NLD];
                 bool ok = false;
                 // (A one-lane hint poll ahead of this loop, or pauses between the polls: 275 -> 270-272 us at hidden 1024, nothing at 512.)
@@ -3289,11 +3301,21 @@ size_t fwd_halves_bf16_ring_halfwords(int N, int B) { return (size_t)HX_RING * N
     } while (0)
 // columns one launch takes: as many 8-column groups as are co-resident, one workgroup per CU (a wider batch runs as several
 // launches over column ranges -- the streams are independent recurrences)
-int fwd_halves_bf16_launch_cols(int N, int n_cus) { return 8 * (n_cus / (N / fwd_halves_bf16_units(N))); }
+// Columns per workgroup: 8 (two alternating halves), or 4 -- one half per workgroup, twice the workgroups -- where the whole
+// batch then still fits one launch: narrow batches leave XCDs idle (configs[4]: 16 streams = two 8-column groups on two
+// XCDs), and a workgroup with one half never has that half's data waiting behind the other half's matrix phase.
+int bf16_group_cols(int N, int B, int n_cus) {
+    static const int force = getenv("LSTM_HIP_BF16_GCOLS") ? atoi(getenv("LSTM_HIP_BF16_GCOLS")) : 0; // A/B: 4 or 8
+    const int fit = n_cus / (N / fwd_halves_bf16_units(N)); // groups of one launch
+    if (force == 8 || B % 4 != 0 || (B + 3) / 4 > fit) return 8;
+    if (force == 4) return 4;
+    return BF16_SINGLE_HALF_DEFAULT ? 4 : 8;
+}
+int fwd_halves_bf16_launch_cols(int N, int B, int n_cus) { return bf16_group_cols(N, B, n_cus) * (n_cus / (N / fwd_halves_bf16_units(N))); }
 bool fwd_halves_bf16_supported(int N, int B, int n_cus) {
     if (N != 256 && N != 512 && N != 1024) return false;
     if (B % 4 != 0) return false; // 8-byte ring pieces and Hb rows
-    if (fwd_halves_bf16_launch_cols(N, n_cus) < 8) return false;
+    if (n_cus / (N / fwd_halves_bf16_units(N)) < 1) return false;
     int per_cu = 0;
 #define GO(n, u)                                                                                                                  \
     per_cu = blocks_per_cu(k_fwd_halves_bf16<n, u, false>, FwdhbShape<n, u>::THREADS, FwdhbShape<n, u>::LDS) > 0 &&               \
@@ -3308,12 +3330,13 @@ bool fwd_halves_bf16_supported(int N, int B, int n_cus) {
 void fwd_halves_bf16(const void *Ufwd6b, const float *W, const float *bias, float *H, unsigned short *Hb, float *C, float *G,
                      const int32_t *xi, void *Hxb, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S,
                      int B, int col0, int cols, bool fast, int n_cus, hipStream_t st, unsigned long long *stamps) {
-    const int NB = N / fwd_halves_bf16_units(N), NG = (cols + 7) / 8;
+    const int GC = bf16_group_cols(N, B, n_cus);
+    const int NB = N / fwd_halves_bf16_units(N), NG = (cols + GC - 1) / GC;
     static const bool no_pin = getenv("LSTM_HIP_NO_PIN") && atoi(getenv("LSTM_HIP_NO_PIN")); // A/B
     const int pinned = NG < 8 && 8 * NB <= n_cus && !no_pin;
     const dim3 grid(pinned ? 8 * NB : NB * NG);
     const FwdhbArgs args = {reinterpret_cast<const uint2 *>(Ufwd6b), W, bias, H, Hb, C, G, xi, reinterpret_cast<unsigned *>(Hxb), cnt, abortp,
-                            epoch, ring_base, S, B, NG, pinned, col0, stamps};
+                            epoch, ring_base, S, B, NG, pinned, col0, GC, stamps};
 #define GO(n, u)                                                                                                               \
     do {                                                                                                                       \
         if (stamps) hipLaunchKernelGGL((k_fwd_halves_bf16<n, u, false, true>), grid, dim3(FwdhbShape<n, u>::THREADS), (FwdhbShape<n, u>::LDS), st, args); \
@@ -3428,7 +3451,8 @@ void bwd_scatter(const float4 *Ubwd6, float *DG, const float *Why, const float *
 int bwd_scatter_bf16_units(int N) { return N == 1024 ? 32 : 16; }
 // publication number of the next launch's first hand-off (slot = low two bits, parity = bit 2)
 int bwd_scatter_bf16_ring_advance(int base, int S) { return (base + (S > 2 ? S - 2 : 0)) & 7; }
-int bwd_scatter_bf16_launch_cols(int N, int n_cus) { return 8 * (n_cus / (N / bwd_scatter_bf16_units(N))); }
+int bf16_group_cols(int N, int B, int n_cus);
+int bwd_scatter_bf16_launch_cols(int N, int B, int n_cus) { return bf16_group_cols(N, B, n_cus) * (n_cus / (N / bwd_scatter_bf16_units(N))); }
 size_t bwd_scatter_bf16_ring_floats(int N, int B, int n_cus) {
     (void)n_cus;
     return bwdsb_ring_floats(N, bwd_scatter_bf16_units(N), B); // a region per column group of the whole batch
@@ -3436,7 +3460,7 @@ size_t bwd_scatter_bf16_ring_floats(int N, int B, int n_cus) {
 bool bwd_scatter_bf16_supported(int N, int B, int n_cus) {
     if (N != 256 && N != 512 && N != 1024) return false;
     (void)B;
-    if (bwd_scatter_bf16_launch_cols(N, n_cus) < 8) return false;
+    if (n_cus / (N / bwd_scatter_bf16_units(N)) < 1) return false;
     int per_cu = 0;
     if (N == 1024) per_cu = blocks_per_cu(k_bwd_scatter_bf16<1024, 32>, BwdsbShape<1024, 32>::THREADS);
     else if (N == 512) per_cu = blocks_per_cu(k_bwd_scatter_bf16<512, 16>, BwdsbShape<512, 16>::THREADS);
@@ -3447,11 +3471,12 @@ bool bwd_scatter_bf16_supported(int N, int B, int n_cus) {
 void bwd_scatter_bf16(const void *Ubwd6b, float *DG, const float *DHy, const float *G, const float *C, float *Qx, unsigned *cnt,
                       unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int col0, int cols, int n_cus, hipStream_t st,
                       unsigned long long *stamps) {
-    const int NB = N / bwd_scatter_bf16_units(N), NG = (cols + 7) / 8;
+    const int GC = bf16_group_cols(N, B, n_cus);
+    const int NB = N / bwd_scatter_bf16_units(N), NG = (cols + GC - 1) / GC;
     static const int spread = getenv("LSTM_HIP_BWD_SPREAD") && atoi(getenv("LSTM_HIP_BWD_SPREAD")) ? 1 : 0;
     const int pinned = NG < 8 && 8 * NB <= n_cus && !spread;
     const dim3 grid(pinned ? 8 * NB : NB * NG);
-    const BwdsbArgs args = {reinterpret_cast<const uint2 *>(Ubwd6b), DG, DHy, G, C, Qx, cnt, abortp, epoch, ring_base, S, B, NG, pinned, col0, stamps};
+    const BwdsbArgs args = {reinterpret_cast<const uint2 *>(Ubwd6b), DG, DHy, G, C, Qx, cnt, abortp, epoch, ring_base, S, B, NG, pinned, col0, GC, stamps};
     if (N == 1024 && stamps) hipLaunchKernelGGL((k_bwd_scatter_bf16<1024, 32, true>), grid, dim3(BwdsbShape<1024, 32>::THREADS), 0, st, args);
     else if (N == 1024) hipLaunchKernelGGL((k_bwd_scatter_bf16<1024, 32>), grid, dim3(BwdsbShape<1024, 32>::THREADS), 0, st, args);
     else if (N == 512 && stamps) hipLaunchKernelGGL((k_bwd_scatter_bf16<512, 16, true>), grid, dim3(BwdsbShape<512, 16>::THREADS), 0, st, args);

@@ -133,6 +133,6 @@ int main() {
     }
     int clk = 0;
     hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
-    printf("(s_memtime runs at a fixed 100 MHz on this part; shader clock attribute %d kHz)\n", clk);
+    printf("(ticks are s_memtime counts, about one per shader cycle at the stamped launches; shader clock attribute %d kHz)\n", clk);
     return 0;
 }
