@@ -2292,7 +2292,7 @@ __host__ __device__ inline size_t bwdsb_ring_floats(int N, int UW, int B) {
 #define BWDSB_TAGGED 1
 #endif
 #ifndef BF16_SINGLE_HALF_DEFAULT
-#define BF16_SINGLE_HALF_DEFAULT 0
+#define BF16_SINGLE_HALF_DEFAULT 1
 #endif
 __device__ __forceinline__ float bwdsb_mark(float v, unsigned phase) {
     if (!BWDSB_TAGGED) return hx_canon(v);
@@ -3302,8 +3302,11 @@ size_t fwd_halves_bf16_ring_halfwords(int N, int B) { return (size_t)HX_RING * N
 // columns one launch takes: as many 8-column groups as are co-resident, one workgroup per CU (a wider batch runs as several
 // launches over column ranges -- the streams are independent recurrences)
 // Columns per workgroup: 8 (two alternating halves), or 4 -- one half per workgroup, twice the workgroups -- where the whole
-// batch then still fits one launch: narrow batches leave XCDs idle (configs[4]: 16 streams = two 8-column groups on two
-// XCDs), and a workgroup with one half never has that half's data waiting behind the other half's matrix phase.
+// batch then still fits ONE launch.  Narrow batches leave XCDs idle (configs[4]: 16 streams = two 8-column groups on two
+// XCDs), and a workgroup with one half never has that half's data waiting behind the other half's matrix phase.  Measured
+// (forward / backward / window): N=1024 B=16 259 / 280 us, 0.708 ms -> 212 / 219 us, 0.601 ms; B=32 260 / 286 -> 215 / 223;
+// N=512 B=16 141 / 172 -> 137 / 156; N=256 B=32 134 / 128 -> 128 / 115.  (A batch that would need a second launch with
+// 4-column groups keeps 8: hidden 1024 with 64 streams is one launch of 625 us, not two of 435.)
 int bf16_group_cols(int N, int B, int n_cus) {
     static const int force = getenv("LSTM_HIP_BF16_GCOLS") ? atoi(getenv("LSTM_HIP_BF16_GCOLS")) : 0; // A/B: 4 or 8
     const int fit = n_cus / (N / fwd_halves_bf16_units(N)); // groups of one launch
