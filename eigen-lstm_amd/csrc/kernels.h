@@ -110,7 +110,7 @@ int bwd_scatter_bf16_units(int N);
 int bwd_scatter_bf16_ring_advance(int base, int S);
 void bwd_scatter_bf16(const void *Ubwd6b, float *DG, const float *DHy, const float *G, const float *C, float *Qx, unsigned *cnt,
                       unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int col0, int cols, int n_cus, hipStream_t st,
-                      unsigned long long *stamps);
+                      unsigned long long *stamps, unsigned short *DGt_b = nullptr, int Tpad = 0);
 size_t bwd_partial_floats(int N);
 int bwd_group_cols(int N, int B, int n_cus); // 8 or 16 batch columns per backward workgroup
 

@@ -107,6 +107,7 @@ struct lstm_hip_ctx {
     bool bwd_scatter16 = false;                   // bf16 backward recurrence in its scatter form (k_bwd_scatter_bf16)
     void *Ufwd6b = nullptr, *Hxb = nullptr;       // two-half bf16 forward form: weights image, bf16 hand-off ring
     bool fwd_halves16 = false;
+    bool dgt_written = false;                     // the backward recurrence wrote the transposed bf16 image of dg itself
     bool packed6b = false;                        // Ubwd6b is current (written by the Adagrad launch)
     // bf16 operands of the four time-batched products, k contiguous (kernels.h, gemm_bf16): Why^T and Why; per window
     // h^T [N][SBpad], dy^T [256][Tpad], dg^T [4N][Tpad] and dy [T][256]
@@ -399,13 +400,21 @@ int do_backward(lstm_hip_ctx *h) {
             h->bwd_epoch = 0;
         }
         h->bwd_epoch++;
+        h->dgt_written = false;
         if (h->bf16 && h->bwd_scatter16) {
             const int lc = bwd_scatter_bf16_launch_cols(N, B, h->n_cus); // one launch per co-resident range of columns
+            static const bool no_direct = getenv("LSTM_HIP_NO_DIRECT_DGT") && atoi(getenv("LSTM_HIP_NO_DIRECT_DGT")); // A/B
+            // The recurrence writes the k-contiguous bf16 image of dg for the dU product itself (2-byte stores, off the chain)
+            // where that is cheaper than the transposing pass behind it: measured at N=1024 with 16 streams 0.5776 -> 0.5701 ms
+            // (recurrence +4 us, dU launch -9); with 64 streams the scattered stores cost the recurrence what the pass costs
+            // (N=512: +19 / -18 us) and with 128 more (+76 / -71 us per window), so only for the narrow batches.
+            const bool direct_dgt = !no_direct && N == 1024 && B <= 32;
+            h->dgt_written = direct_dgt;
             for (int c0 = 0; c0 < B; c0 += lc) {
                 if (c0 > 0) h->bwd_epoch++;
                 RUN(K_BWD_PERSIST, bwd_scatter_bf16(h->Ubwd6b, h->DG, h->DHy, h->G, h->C, h->DGx, cb, h->abortp, h->bwd_epoch,
                                                     h->ring_base_b, N, S, B, c0, B - c0 < lc ? B - c0 : lc, h->n_cus, h->st,
-                                                    h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr));
+                                                    h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr, direct_dgt ? h->DGt_b : nullptr, h->Tpad));
             }
             h->ring_base_b = bwd_scatter_bf16_ring_advance(h->ring_base_b, S); // (every group's region has had its S - 2 publications)
         } else if (h->bf16) {
@@ -518,7 +527,7 @@ int do_backward(lstm_hip_ctx *h) {
     // dU = DG * H[0..S-2]^T            R/lstm.cc:250
     if (h->bf16) { // dg_t pairs with h_{t-1}: column (t-1)*B+b of both images
         h->n_slabs_dU = 0;
-        RUN(K_GEMM_DU, (transpose_pack_bf16(h->DG + (size_t)G4 * B, T, G4, G4, h->DGt_b, h->Tpad, h->st),
+        RUN(K_GEMM_DU, (h->dgt_written ? (void)0 : transpose_pack_bf16(h->DG + (size_t)G4 * B, T, G4, G4, h->DGt_b, h->Tpad, h->st),
                         gemm_bf16(G4, N, h->Tpad, h->DGt_b, h->Tpad, h->Ht_b, h->SBpad, h->dP + h->pl.U, G4, h->splits_dU,
                                   h->slabs_dU, h->st)));
     } else if (defer_fold && h->splits_dU > 1)

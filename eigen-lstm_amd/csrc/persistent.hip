@@ -2270,6 +2270,8 @@ struct BwdsbArgs {
     unsigned *cnt, *abortp;
     unsigned epoch;
     int ring_base, S, B, NG, pinned, col0, gcols; // columns col0 .. col0 + gcols*NG - 1 of the B
+    unsigned short *DGt_b;                          // or null: transposed bf16 image of dg, [4N][Tpad]
+    int Tpad;
     unsigned long long *stamps;
 };
 // UW = units per workgroup: 16, or 32 where a group of N/16 workgroups would not fit one XCD (hidden 1024: 32 workgroups of
@@ -2553,6 +2555,13 @@ __global__ __launch_bounds__((BwdsbShape<N_, UW>::THREADS)) void k_bwd_scatter_b
                     t2 = r0;
                     t3 = r1;
                 }
+            }
+            if (ecol < B && p.DGt_b != nullptr) { // the k-contiguous bf16 image the dU product reads: row = gate row, column (t-1)*B + stream
+                unsigned short *q = p.DGt_b + (size_t)j * p.Tpad + (size_t)(t - 1) * B + ecol;
+                q[0] = __builtin_bit_cast(unsigned short, (__bf16)d_i);
+                q[(size_t)N * p.Tpad] = __builtin_bit_cast(unsigned short, (__bf16)d_o);
+                q[(size_t)2 * N * p.Tpad] = __builtin_bit_cast(unsigned short, (__bf16)d_f);
+                q[(size_t)3 * N * p.Tpad] = __builtin_bit_cast(unsigned short, (__bf16)d_u);
             }
             if (ecol < B) {
                 const float4 v = {t0, t1, t2, t3};
@@ -3473,13 +3482,13 @@ bool bwd_scatter_bf16_supported(int N, int B, int n_cus) {
 // one launch: columns [col0, col0 + cols) of the B, cols <= bwd_scatter_bf16_launch_cols
 void bwd_scatter_bf16(const void *Ubwd6b, float *DG, const float *DHy, const float *G, const float *C, float *Qx, unsigned *cnt,
                       unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int col0, int cols, int n_cus, hipStream_t st,
-                      unsigned long long *stamps) {
+                      unsigned long long *stamps, unsigned short *DGt_b, int Tpad) {
     const int GC = bf16_group_cols(N, B, n_cus);
     const int NB = N / bwd_scatter_bf16_units(N), NG = (cols + GC - 1) / GC;
     static const int spread = getenv("LSTM_HIP_BWD_SPREAD") && atoi(getenv("LSTM_HIP_BWD_SPREAD")) ? 1 : 0;
     const int pinned = NG < 8 && 8 * NB <= n_cus && !spread;
     const dim3 grid(pinned ? 8 * NB : NB * NG);
-    const BwdsbArgs args = {reinterpret_cast<const uint2 *>(Ubwd6b), DG, DHy, G, C, Qx, cnt, abortp, epoch, ring_base, S, B, NG, pinned, col0, GC, stamps};
+    const BwdsbArgs args = {reinterpret_cast<const uint2 *>(Ubwd6b), DG, DHy, G, C, Qx, cnt, abortp, epoch, ring_base, S, B, NG, pinned, col0, GC, DGt_b, Tpad, stamps};
     if (N == 1024 && stamps) hipLaunchKernelGGL((k_bwd_scatter_bf16<1024, 32, true>), grid, dim3(BwdsbShape<1024, 32>::THREADS), 0, st, args);
     else if (N == 1024) hipLaunchKernelGGL((k_bwd_scatter_bf16<1024, 32>), grid, dim3(BwdsbShape<1024, 32>::THREADS), 0, st, args);
     else if (N == 512 && stamps) hipLaunchKernelGGL((k_bwd_scatter_bf16<512, 16, true>), grid, dim3(BwdsbShape<512, 16>::THREADS), 0, st, args);
