@@ -111,6 +111,12 @@ int bwd_scatter_bf16_ring_advance(int base, int S);
 void bwd_scatter_bf16(const void *Ubwd6b, float *DG, const float *DHy, const float *G, const float *C, float *Qx, unsigned *cnt,
                       unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, int col0, int cols, int n_cus, hipStream_t st,
                       unsigned long long *stamps, unsigned short *DGt_b = nullptr, int Tpad = 0);
+// one stream, hidden 64 / 128: both recurrences on one CU (k_small_fwd, k_small_bwd); they read U and Why as stored, write H, C,
+// G and DG (the backward one reads U from the Ubwd tile image); the backward one computes Why^T dy itself (no DHy), dW / db / dWhy / dU are the unfused path's launches
+bool small_recurrence_supported(int N, int B);
+void small_fwd(const float *U, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi, int N, int S, bool fast,
+               hipStream_t st);
+void small_bwd(const float4 *Ubwd, const float *Why, const float *dY, const float *G, const float *C, float *DG, int N, int S, hipStream_t st);
 size_t bwd_partial_floats(int N);
 int bwd_group_cols(int N, int B, int n_cus); // 8 or 16 batch columns per backward workgroup
 

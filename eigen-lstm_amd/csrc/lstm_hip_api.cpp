@@ -107,6 +107,7 @@ struct lstm_hip_ctx {
     bool bwd_scatter16 = false;                   // bf16 backward recurrence in its scatter form (k_bwd_scatter_bf16)
     void *Ufwd6b = nullptr, *Hxb = nullptr;       // two-half bf16 forward form: weights image, bf16 hand-off ring
     bool fwd_halves16 = false;
+    bool small = false;                           // one stream, hidden <= 128: both recurrences on one CU (k_small_fwd / k_small_bwd)
     bool dgt_written = false;                     // the backward recurrence wrote the transposed bf16 image of dg itself
     bool packed6b = false;                        // Ubwd6b is current (written by the Adagrad launch)
     // bf16 operands of the four time-batched products, k contiguous (kernels.h, gemm_bf16): Why^T and Why; per window
@@ -269,6 +270,10 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
         h->fwd_epoch = 0;
     }
     h->fwd_epoch++;
+    if (h->small) {
+        RUN(K_FWD_PERSIST, small_fwd(h->P + h->pl.U, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, N, S, fast, h->st));
+        return 0;
+    }
     if (h->bf16) {
         if (!h->packed16) {
             // (the one-recurrence forms' images only where one of them runs)
@@ -375,7 +380,7 @@ int do_backward(lstm_hip_ctx *h) {
     if (h->bf16) { // DHy = Why^T * dY on bf16 operands: both already have the contraction index m contiguous
         RUN(K_GEMM_DHY, (pack_bf16(dY, (size_t)T * 256, h->dYb, h->st),
                          gemm_bf16(N, T, 256, h->Why_b, 256, h->dYb, 256, h->DHy + (size_t)N * B, N, 1, nullptr, h->st)));
-    } else if (!fused && !h->bwd_halves) // (the two-half backward form computes Why^T dy itself)
+    } else if (!fused && !h->bwd_halves && !h->small) // (the two-half and the single-CU backward forms compute Why^T dy themselves)
         RUN(K_GEMM_DHY, gemm(true, false, N, T, 256, h->P + h->pl.Why, 256, dY, 256, h->DHy + (size_t)N * B, N, 1, nullptr,
                              h->st));
     // Unfused two-half form, single GPU: the sums that do not feed the recurrence run on st2 beside it -- the column sort of
@@ -401,7 +406,9 @@ int do_backward(lstm_hip_ctx *h) {
         }
         h->bwd_epoch++;
         h->dgt_written = false;
-        if (h->bf16 && h->bwd_scatter16) {
+        if (h->small) {
+            RUN(K_BWD_PERSIST, small_bwd(h->Ubwd, h->P + h->pl.Why, dY, h->G, h->C, h->DG, N, S, h->st));
+        } else if (h->bf16 && h->bwd_scatter16) {
             const int lc = bwd_scatter_bf16_launch_cols(N, B, h->n_cus); // one launch per co-resident range of columns
             static const bool no_direct = getenv("LSTM_HIP_NO_DIRECT_DGT") && atoi(getenv("LSTM_HIP_NO_DIRECT_DGT")); // A/B
             // The recurrence writes the k-contiguous bf16 image of dg for the dU product itself (2-byte stores, off the chain)
@@ -708,10 +715,14 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     ALLOC(h->cnt, 2 * h->cnt_bytes / sizeof(unsigned));
     ALLOC(h->abortp, 4);
     // bf16 path: every product is a bf16 GEMM of its own, nothing is fused into the recurrence
-    const bool want_fused = !(cfg->flags & (LSTM_HIP_NO_FUSED_GRADS | LSTM_HIP_BF16_RECURRENCE)) && cfg->N <= 512; // larger N: one workgroup per CU no longer holds
+    // one stream at hidden <= 128 (the reference's default shape): single-CU recurrences, unfused sums ("0": the multi-CU forms, A/B)
+    const bool small_ok = !(cfg->flags & (LSTM_HIP_STEP_KERNELS | LSTM_HIP_BF16_RECURRENCE)) && small_recurrence_supported(cfg->N, cfg->B) &&
+                          !(getenv("LSTM_HIP_SMALL") && atoi(getenv("LSTM_HIP_SMALL")) == 0);
+    const bool want_fused = !(cfg->flags & (LSTM_HIP_NO_FUSED_GRADS | LSTM_HIP_BF16_RECURRENCE)) && cfg->N <= 512 && !small_ok; // larger N: one workgroup per CU no longer holds
     h->persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) &&                          // the dW table beside the weights
                     persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount, want_fused);
     h->n_cus = prop.multiProcessorCount;
+    h->small = h->persistent && small_ok;
     h->bwd_cols = bwd_group_cols(cfg->N, cfg->B, prop.multiProcessorCount);
     if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) { // refusals: lstm_hip_create, before anything is allocated
         h->persistent = true;                    // ... where the bf16 kernels' own grids were checked
@@ -745,7 +756,7 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
             HIP_TRY(hipMemset(h->DGx, 0xff, sizeof(float) * h->DGx_floats));
         }
     }
-    if (h->persistent && bwd_uses_m4((int)N, h->bwd_cols, h->bf16)) {
+    if (h->persistent && bwd_uses_m4((int)N, h->bwd_cols, h->bf16) && !h->small) { // (the single-CU form reads the tile image Ubwd)
         ALLOC(h->Ubwd4, N * N);
         const char *bh = getenv("LSTM_HIP_BWD_HALVES");
         h->side_stream = !(getenv("LSTM_HIP_NO_SIDE_STREAM") && atoi(getenv("LSTM_HIP_NO_SIDE_STREAM")));

@@ -3189,6 +3189,182 @@ bool persistent_supported_bf16(int N, int B, int n_cus, bool fused) {
     return grid_fits(fwd_grid, fb, n_cus) && grid_fits((size_t)(N / 16) * ((B + cols - 1) / cols), bb, n_cus);
 }
 
+// ------------------------------------------------------------------------------------------------
+// One stream, hidden <= 128 (the reference's own default: R/lstm.cc, alice29, N = 128, S = 25, batch 1 = BASELINE configs[0]):
+// the whole recurrence on ONE CU.  U (4N x N fp32 = 256 KB at N = 128) fits the register file of one 1024-thread workgroup,
+// so a step needs no hand-off between CUs at all -- two or three workgroup barriers instead of an L2 round trip (the
+// 16-workgroup form took 2.4 us a step at this shape).
+//   forward : thread (row, k-part) keeps U[row][its N/KP values of k]; step = partial dot products -> LDS -> the N threads of
+//             the units add the parts and W[:, x_t] + b, gates / cell (R/lstm.cc:176-192), h_t to LDS and H / C / G
+//   backward: thread (unit j, row-part) keeps U[its 4N/RQ rows][j] (from the Ubwd tile image) and Why[its 256/RQ rows][j]; step = partial sums of
+//             U^T dg_{t+1} + Why^T dy_t (R/lstm.cc:228) -> LDS -> unit threads: R/lstm.cc:233-247,256, dg_t to LDS and DG
+// dW, db, dWhy, dU are the time-batched launches of the unfused path.
+// ------------------------------------------------------------------------------------------------
+// (workgroup barrier for LDS traffic only: __syncthreads() also waits for the wave's global stores -- H, C, G, DG of the step,
+// about a microsecond each time -- which nothing in these kernels reads back)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N_, bool FAST>
+__global__ __launch_bounds__(1024) void k_small_fwd(const float *__restrict__ U, const float *__restrict__ W, const float *__restrict__ bias,
+                                                    float *__restrict__ H, float *__restrict__ C, float *__restrict__ G,
+                                                    const int32_t *__restrict__ xi, int S) {
+    constexpr int N = N_, G4 = 4 * N, KP = 1024 / G4, KW = N / KP;
+    static_assert(N == 128 || N == 64, "single-CU form: hidden 64 or 128");
+    __shared__ __attribute__((aligned(16))) float hs[N];
+    __shared__ float part[KP][G4];
+    const int tid = threadIdx.x, row = tid % G4, kp = tid / G4;
+    float u[KW];
+#pragma unroll
+    for (int i = 0; i < KW; i++) u[i] = U[(size_t)(kp * KW + i) * G4 + row];
+    float cprev = 0.0f, bs[4] = {0.f, 0.f, 0.f, 0.f}, wx[4] = {0.f, 0.f, 0.f, 0.f};
+    auto gather = [&](int t) { // W[:, x_t] (R/lstm.cc:176 with a one-hot x), requested a step ahead
+#pragma unroll
+        for (int g = 0; g < 4; g++) wx[g] = 0.f;
+        const int x = xi[t];
+        if (x >= 0) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) wx[g] = W[(size_t)x * G4 + g * N + tid];
+        }
+    };
+    if (tid < N) {
+        hs[tid] = H[tid];
+        cprev = C[tid];
+#pragma unroll
+        for (int g = 0; g < 4; g++) bs[g] = bias[g * N + tid];
+        gather(1);
+    }
+    __syncthreads();
+    for (int t = 1; t < S; t++) {
+        f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f}; // v_pk_fma_f32: two multiply-adds per lane and instruction
+#pragma unroll
+        for (int i = 0; i < KW; i += 4) {
+            const float4 hv = *reinterpret_cast<const float4 *>(hs + kp * KW + i); // same address in every lane: a broadcast read
+            a01 = __builtin_elementwise_fma(f32x2_t{u[i + 0], u[i + 1]}, f32x2_t{hv.x, hv.y}, a01);
+            a23 = __builtin_elementwise_fma(f32x2_t{u[i + 2], u[i + 3]}, f32x2_t{hv.z, hv.w}, a23);
+        }
+        part[kp][row] = (a01[0] + a01[1]) + (a23[0] + a23[1]);
+        lds_barrier();
+        if (tid < N) {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float uh = part[0][g * N + tid];
+#pragma unroll
+                for (int q = 1; q < KP; q++) uh += part[q][g * N + tid];
+                pre[g] = (wx[g] + uh) + bs[g]; // R/lstm.cc:176
+            }
+            const float ig = p_sigm<FAST>(pre[0]), og = p_sigm<FAST>(pre[1]), fg = p_sigm<FAST>(pre[2]); // :179
+            const float ug = p_tanh<FAST>(pre[3]);                                                        // :182
+            const float cv = p_tanh<FAST>(ig * ug + fg * cprev);                                          // :185-189
+            const float hv = og * cv;                                                                     // :192
+            cprev = cv;
+            hs[tid] = hv;
+            if (t + 1 < S) gather(t + 1);
+            H[(size_t)t * N + tid] = hv;
+            C[(size_t)t * N + tid] = cv;
+            float *gc = G + (size_t)t * G4 + tid;
+            gc[0] = ig;
+            gc[N] = og;
+            gc[2 * N] = fg;
+            gc[3 * N] = ug;
+        }
+        lds_barrier();
+    }
+}
+// (512 threads: a thread's 128 + 64 weights at hidden 128 need the 256-register budget of eight waves)
+constexpr int SMALL_BWD_THREADS = 512;
+template <int N_>
+__global__ __launch_bounds__(SMALL_BWD_THREADS) void k_small_bwd(const float4 *__restrict__ Ubwd, const float *__restrict__ Why, const float *__restrict__ dY,
+                                                    const float *__restrict__ G, const float *__restrict__ C, float *__restrict__ DG, int S) {
+    constexpr int NT = SMALL_BWD_THREADS, N = N_, G4 = 4 * N, RQ = NT / N, RW = G4 / RQ, MW = 256 / RQ;
+    static_assert(N == 128 || N == 64, "single-CU form: hidden 64 or 128");
+    __shared__ __attribute__((aligned(16))) float dgs[G4];
+    __shared__ __attribute__((aligned(16))) float dys[256];
+    __shared__ float part[RQ][N];
+    const int tid = threadIdx.x, j = tid % N, rq = tid / N;
+    // The thread's weights: U[its 4N/RQ rows][j] from the tile image Ubwd (k_pack_U / k_adagrad: one float4 = four consecutive
+    // rows of a column, sixteen columns side by side -- 256-byte runs across a wave) and Why[its 256/RQ output rows][j]
+    // (contiguous along the rows for a fixed j: 16-byte pieces, all requested at once).
+    float ub[RW], wy[MW];
+#pragma unroll
+    for (int i = 0; i < RW; i += 4) {
+        const int r = rq * RW + i;
+        const float4 v = Ubwd[((size_t)(j >> 4) * (N / 4) + (r >> 4)) * 64 + (((r & 15) >> 2) << 4) + (j & 15)];
+        ub[i] = v.x, ub[i + 1] = v.y, ub[i + 2] = v.z, ub[i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < MW; i += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(Why + (size_t)j * 256 + rq * MW + i);
+        wy[i] = v.x, wy[i + 1] = v.y, wy[i + 2] = v.z, wy[i + 3] = v.w;
+    }
+    for (int i = tid; i < G4; i += NT) dgs[i] = 0.0f; // dhnext = 0, R/lstm.cc:216
+    float dcn = 0.0f;                                  // dcnext, :217
+    // operands of a step are requested a step ahead: dy_t (256 threads), gates and cells of the unit threads
+    float dyv = tid < 256 ? dY[(size_t)(S - 2) * 256 + tid] : 0.0f;
+    float ig = 0.f, og = 0.f, fg = 0.f, ug = 0.f, cv = 0.f, cp = 0.f;
+    auto fetch = [&](int t) {
+        const float *gc = G + (size_t)t * G4 + tid;
+        ig = gc[0], og = gc[N], fg = gc[2 * N], ug = gc[3 * N];
+        cv = C[(size_t)t * N + tid], cp = C[(size_t)(t - 1) * N + tid];
+    };
+    if (tid < N) fetch(S - 1);
+    for (int t = S - 1; t >= 1; t--) {
+        if (tid < 256) {
+            dys[tid] = dyv;
+            if (t >= 2) dyv = dY[(size_t)(t - 2) * 256 + tid];
+        }
+        lds_barrier();
+        f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MW; i += 4) { // Why^T dy_t
+            const float4 v = *reinterpret_cast<const float4 *>(dys + rq * MW + i);
+            a01 = __builtin_elementwise_fma(f32x2_t{wy[i + 0], wy[i + 1]}, f32x2_t{v.x, v.y}, a01);
+            a23 = __builtin_elementwise_fma(f32x2_t{wy[i + 2], wy[i + 3]}, f32x2_t{v.z, v.w}, a23);
+        }
+#pragma unroll
+        for (int i = 0; i < RW; i += 4) { // U^T dg_{t+1}
+            const float4 v = *reinterpret_cast<const float4 *>(dgs + rq * RW + i);
+            a01 = __builtin_elementwise_fma(f32x2_t{ub[i + 0], ub[i + 1]}, f32x2_t{v.x, v.y}, a01);
+            a23 = __builtin_elementwise_fma(f32x2_t{ub[i + 2], ub[i + 3]}, f32x2_t{v.z, v.w}, a23);
+        }
+        part[rq][j] = (a01[0] + a01[1]) + (a23[0] + a23[1]);
+        lds_barrier();
+        if (tid < N) {
+            float dh = part[0][tid]; // R/lstm.cc:228
+#pragma unroll
+            for (int q = 1; q < RQ; q++) dh += part[q][tid];
+            float dcv = dh * og + dcn;                          // :233
+            dcv = dcv * (1.0f - cv * cv);                       // :235
+            const float d_o = (dh * cv) * (og * (1.0f - og));   // :238,244
+            const float d_i = (dcv * ug) * (ig * (1.0f - ig));  // :239,244
+            const float d_f = (dcv * cp) * (fg * (1.0f - fg));  // :240,244
+            const float d_u = (dcv * ig) * (1.0f - ug * ug);    // :241,247
+            dcn = dcv * fg;                                     // :256
+            dgs[tid] = d_i, dgs[N + tid] = d_o, dgs[2 * N + tid] = d_f, dgs[3 * N + tid] = d_u;
+            if (t >= 2) fetch(t - 1);
+            float *dp = DG + (size_t)t * G4 + tid;
+            dp[0] = d_i, dp[N] = d_o, dp[2 * N] = d_f, dp[3 * N] = d_u;
+        }
+        lds_barrier();
+    }
+}
+bool small_recurrence_supported(int N, int B) { return B == 1 && (N == 128 || N == 64); }
+void small_fwd(const float *U, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi, int N, int S, bool fast,
+               hipStream_t st) {
+#define GO(n)                                                                                                     \
+    do {                                                                                                          \
+        if (fast) hipLaunchKernelGGL((k_small_fwd<n, true>), dim3(1), dim3(1024), 0, st, U, W, bias, H, C, G, xi, S);  \
+        else hipLaunchKernelGGL((k_small_fwd<n, false>), dim3(1), dim3(1024), 0, st, U, W, bias, H, C, G, xi, S);      \
+    } while (0)
+    if (N == 128) GO(128);
+    else GO(64);
+#undef GO
+}
+void small_bwd(const float4 *Ubwd, const float *Why, const float *dY, const float *G, const float *C, float *DG, int N, int S, hipStream_t st) {
+    if (N == 128) hipLaunchKernelGGL((k_small_bwd<128>), dim3(1), dim3(SMALL_BWD_THREADS), 0, st, Ubwd, Why, dY, G, C, DG, S);
+    else hipLaunchKernelGGL((k_small_bwd<64>), dim3(1), dim3(SMALL_BWD_THREADS), 0, st, Ubwd, Why, dY, G, C, DG, S);
+}
+
 // ---- forward ---------------------------------------------------------------------------------------------------------
 void fwd_persistent(const float4 *Ufwd, const float *W, const float *bias, float *H, float *C, float *G,
                     const int32_t *xi, unsigned *cnt, unsigned *abortp, unsigned epoch, int N, int S, int B, bool fast,

@@ -785,9 +785,10 @@ def test_create_destroy_does_not_leak():
 
 # (256, 9, 72): 9 column groups, the unpinned placement; (512, 7, 16) / (1024, ...): fewer than 8 groups, one group pinned to
 # each XCD; (1024, 5, 64): hidden 1024 with 8 groups of 32 workgroups -- the whole chip, one workgroup per CU; (1024, 4, 128)
-# and (512, 6, 88): wider than that, two launches per direction over column ranges (64 + 64, 64 + 24)
+# and (512, 6, 88): wider than that, two launches per direction over column ranges (64 + 64, 64 + 24); (256, 42, 64): a window
+# of 2 624 columns, past the one-pass dW / db kernel's limit (the sort + segment-sum passes; every shorter case takes the table)
 @pytest.mark.parametrize("N,S,B", [(128, 6, 8), (256, 10, 24), (256, 9, 72), (512, 12, 64), (512, 7, 16), (1024, 4, 16),
-                                   (1024, 5, 64), (1024, 4, 128), (512, 6, 88)])
+                                   (1024, 5, 64), (1024, 4, 128), (512, 6, 88), (256, 42, 64)])
 def test_bf16_recurrence_matches_bf16_oracle(N, S, B, oracle32):
     """LSTM_HIP_BF16_RECURRENCE (BASELINE configs[4] semantics: bf16 MFMA operands in the two recurrent and the four
     time-batched products, fp32 accumulate and fp32 everything else) against the oracle in the same mode (those operands
