@@ -65,7 +65,11 @@ void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, flo
 bool fwd_uses_two_half_form(int N, int B, int n_cus);
 void fwd_persistent6(const float4 *Ufwd5, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
-                     int poll_cfg, hipStream_t st, unsigned long long *stamps = nullptr);
+                     int poll_cfg, hipStream_t st, unsigned long long *stamps = nullptr, int col0 = 0, int cols = 0);
+// columns one launch of the fp32 two-half forms takes; a wider batch (two_half_wide) runs as launches over column ranges
+// [col0, col0 + cols) -- cols = 0: the whole batch
+int two_half_launch_cols(int N, int n_cus);
+bool two_half_wide(int N, int B, int n_cus);
 // two-half (scatter) form of the backward recurrence (N = 512 / 256, 8-column groups): every workgroup advances its eight
 // columns as two alternating 4-column recurrences, multiplies its OWN dg_t into partial sums for all N outputs and scatters
 // them to the owners of the outputs.  Ubwd6 image (pack_U / adagrad with bit 2 of half_forms), partial-sum ring Qx
@@ -75,7 +79,7 @@ bool bwd_scatter_supported(int N, int B, int n_cus, bool fused);
 int bwds_ring_advance(int ring_base, int S);
 void bwd_scatter(const float4 *Ubwd6, float *DG, const float *Why, const float *dY, const float *G, const float *C, const float *H,
                  const int32_t *xi, float *gpart, float *Qx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N,
-                 int S, int B, int cfg, hipStream_t st, unsigned long long *stamps = nullptr);
+                 int S, int B, int cfg, hipStream_t st, unsigned long long *stamps = nullptr, int col0 = 0, int cols = 0);
 // gpart != null (8-column groups only): fused mode.  The recurrence then also produces DHy on the fly from
 // Why and dY (DHy is not read), and leaves per-column-group partial blocks [dW | - | db | dWhy]
 // (bwd_partial_floats(N) floats each) to be folded in group order; H and xi are read as well.

@@ -295,10 +295,15 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
         }
         RUN(K_FWD_PERSIST, fwd_persistent_bf16(h->Ufwd16, h->P + h->pl.W, h->P + h->pl.b, h->H, h->Hb, h->C, h->G, h->xi,
                                                h->cnt, h->abortp, h->fwd_epoch, N, S, B, fast, h->st, h->n_cus));
-    } else if (h->Hx && h->fwd_cols4) {
-        RUN(K_FWD_PERSIST, fwd_persistent6(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
-                                           h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st, h->stamps));
-        h->ring_base = fwd_ring_advance(h->ring_base, S);
+    } else if (h->Hx && h->fwd_cols4) { // as many 8-column groups per launch as are co-resident (one launch unless the batch is wide)
+        const int lc = two_half_launch_cols(N, h->n_cus);
+        for (int c0 = 0; c0 < B; c0 += lc) {
+            if (c0 > 0) h->fwd_epoch++;
+            RUN(K_FWD_PERSIST, fwd_persistent6(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
+                                               h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st, h->stamps, c0,
+                                               B - c0 < lc ? B - c0 : lc));
+        }
+        h->ring_base = fwd_ring_advance(h->ring_base, S); // (every column has made the same S - 1 hand-offs on its part of the ring)
     } else if (h->Hx) {
         RUN(K_FWD_PERSIST, fwd_persistent4(h->Ufwd4, h->P + h->pl.W, h->P + h->pl.b, h->H, h->C, h->G, h->xi, h->Hx, h->cnt,
                                            h->abortp, h->fwd_epoch, h->ring_base, N, S, B, fast, h->poll_cfg, h->st, h->stamps));
@@ -429,9 +434,13 @@ int do_backward(lstm_hip_ctx *h) {
                                               h->xi, fused ? h->gpart : nullptr, h->P + h->pl.Why, dY, cb, h->abortp,
                                               h->bwd_epoch, N, S, B, h->bwd_cols, h->st, nullptr, h->DGb));
         } else if (h->bwd_halves) {
-            RUN(K_BWD_PERSIST, bwd_scatter(h->Ubwd4, h->DG, h->P + h->pl.Why, dY, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr,
-                                           h->DGx, cb, h->abortp, h->bwd_epoch, h->ring_base_b, N, S, B, h->bwd_halves >> 1, h->st,
-                                           h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr));
+            const int lc = two_half_launch_cols(N, h->n_cus); // one launch per co-resident range of columns; every group of the
+            for (int c0 = 0; c0 < B; c0 += lc) {               // batch has its own ring region and partial gradient block
+                if (c0 > 0) h->bwd_epoch++;
+                RUN(K_BWD_PERSIST, bwd_scatter(h->Ubwd4, h->DG, h->P + h->pl.Why, dY, h->G, h->C, h->H, h->xi, fused ? h->gpart : nullptr,
+                                               h->DGx, cb, h->abortp, h->bwd_epoch, h->ring_base_b, N, S, B, h->bwd_halves >> 1, h->st,
+                                               h->stamps ? h->stamps + (size_t)2 * S * 16 : nullptr, c0, B - c0 < lc ? B - c0 : lc));
+            }
             h->ring_base_b = bwds_ring_advance(h->ring_base_b, S);
         } else {
             RUN(K_BWD_PERSIST, bwd_persistent(h->Ubwd4 ? h->Ubwd4 : h->Ubwd, h->DG, h->DHy, h->G, h->C, h->H, h->xi,
@@ -763,7 +772,8 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
         // two-half (scatter) form wherever it exists; "0" selects the one-recurrence form (A/B), other values carry test /
         // tuning bits for the kernel (value >> 1 = its cfg word)
         const int bhv = bh ? atoi(bh) : 1;
-        h->bwd_halves = bhv == 0 ? 0 : (bhv | 1) * (int)bwd_scatter_supported((int)N, (int)B, prop.multiProcessorCount, want_fused);
+        const bool wide = two_half_wide((int)N, (int)B, prop.multiProcessorCount); // (no one-recurrence form there)
+        h->bwd_halves = bhv == 0 && !wide ? 0 : (bhv | 1) * (int)bwd_scatter_supported((int)N, (int)B, prop.multiProcessorCount, want_fused);
         if (h->bwd_halves) { // hand-off through a sentinel ring
             h->DGx_floats = bwd_ring_floats((int)N, (int)B);
             ALLOC(h->DGx, h->DGx_floats);
@@ -772,7 +782,8 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     }
     if (h->persistent && !h->bf16 && fwd_uses_8col_form((int)N, (int)B, prop.multiProcessorCount)) {
         const char *pp = getenv("LSTM_HIP_FWD_HALVES"); // "0": one 8-column recurrence per workgroup (A/B; per handle)
-        h->fwd_cols4 = fwd_uses_two_half_form((int)N, (int)B, prop.multiProcessorCount) && !(pp && atoi(pp) == 0);
+        h->fwd_cols4 = fwd_uses_two_half_form((int)N, (int)B, prop.multiProcessorCount) &&
+                       (!(pp && atoi(pp) == 0) || two_half_wide((int)N, (int)B, prop.multiProcessorCount));
         ALLOC(h->Ufwd4, N * N);
         ALLOC(h->Hx, fwd_ring_floats((int)N, (int)B));
         HIP_TRY(hipMemset(h->Hx, 0xff, sizeof(float) * fwd_ring_floats((int)N, (int)B)));

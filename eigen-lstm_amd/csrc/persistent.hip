@@ -736,6 +736,7 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
     // poll_cfg bits 16-19: pinned launch (fewer than 8 groups): gridDim.y = 8, workgroup i runs on XCD i % 8, group g is the
     // workgroups of XCD g, the workgroups of the other XCDs leave at once
     const int pin_ng = (poll_cfg >> 16) & 15;
+    const int g0 = (poll_cfg >> 20) & 255; // first column group of this launch (a wide batch runs as launches over column ranges)
     const int NB3 = gridDim.x, NG = pin_ng ? pin_ng : (int)gridDim.y;
     const int lin_ = blockIdx.x + NB3 * blockIdx.y;
     const int kb = pin_ng ? lin_ >> 3 : GROUP_REMAP ? lin_ / NG : (int)blockIdx.x;
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
         int colv[2];
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            const int c = 8 * g + 4 * hf + li;
+            const int c = 8 * (g + g0) + 4 * hf + li;
             colv[hf] = c < B ? c : B - 1;
         }
         // h_0 of both halves (plain window state in H); later fragments come from the ring, requested a half-step ahead
@@ -841,7 +842,7 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
         const int hf = w - 8;
         __builtin_amdgcn_s_setprio(3); // the gates are on the chain; the other half's product, issuing beside them, is not
         const int gc = l >> 4, gu = l & 15;
-        const int col = 8 * g + 4 * hf + gc, colc = col < B ? col : B - 1;
+        const int col = 8 * (g + g0) + 4 * hf + gc, colc = col < B ? col : B - 1;
         const int j = 16 * kb + gu;
         float bs[4], cprev, wx[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1643,6 +1644,9 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -
     /* cfg bits 16-19: pinned launch (fewer than 8 groups): gridDim.y = 8, workgroup i runs on XCD i % 8 and group g is the   */ \
     /* workgroups of XCD g; those of the other XCDs leave at once (k_bwd_scatter)                                             */ \
     const int pin_ng_ = (cfg >> 16) & 15;                                                                                       \
+    /* cfg bits 20-27: first column group of this launch (a wide batch runs as launches over column ranges); gq = the group    */ \
+    /* of the whole batch: columns, the partial gradient block and the ring region go by it                                   */ \
+    const int g0_ = (cfg >> 20) & 255, NGT_ = (B + 7) / 8;                                                                      \
     const int NBK = gridDim.x, NG = pin_ng_ ? pin_ng_ : (int)gridDim.y;                                                         \
     const int lin_ = blockIdx.x + NBK * blockIdx.y;                                                                             \
     /* cfg bit 16 (tests): keep the dispatch-order mapping, which spreads every column group over all XCDs -- the placement  */ \
@@ -1650,6 +1654,7 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -
     const bool remap_ = GROUP_REMAP && !(cfg & 16);                                                                             \
     const int kb = pin_ng_ ? lin_ >> 3 : remap_ ? lin_ / NG : (int)blockIdx.x;                                                  \
     const int g = pin_ng_ ? lin_ & 7 : remap_ ? lin_ % NG : (int)blockIdx.y;                                                    \
+    const int gq = g + g0_;                                                                                                     \
     const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DGx, (size_t)HX_RING * G4 * B * sizeof(float));                                \
     unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;                                                               \
     /* a wave that gives up: the abort word ends the launch everywhere, the LDS word releases this workgroup's other waves */   \
@@ -1671,7 +1676,7 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -
         return false;                                                                                                           \
     };                                                                                                                          \
     /* FUSE, after the loops (every wave, at the end of its role): barrier, the dW table and the db / dWhy partial blocks */    \
-    float *base = FUSE ? gpart + (size_t)g * ((size_t)G4 * 256 + (size_t)G4 * N + G4 + (size_t)256 * N) : nullptr;              \
+    float *base = FUSE ? gpart + (size_t)gq * ((size_t)G4 * 256 + (size_t)G4 * N + G4 + (size_t)256 * N) : nullptr;              \
     float *dbs = red; /* epilogue scratch in `red` (free then): [column 0..7][gate][unit] */                                    \
     auto table_out = [&]() { /* dW partial: table row r = gate*16 + unit  ->  gradient row gate*N + 16*kb + unit */             \
         static_assert(BWDH_THREADS == 768, "roles: waves 0-7 product, 8-9 elementwise, 10 dW table, 11 output layer");            \
@@ -1710,7 +1715,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_ou
     int yofs[2];
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
-        const int c = 8 * g + 4 * hf + li;
+        const int c = 8 * gq + 4 * hf + li;
         yofs[hf] = (c < B ? c : B - 1) * 256 + 16 * lY + 4 * lz;
     }
     // (named registers, not arrays: see the note on scratch memory in the git history of this file)
@@ -1751,7 +1756,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_ou
     auto h_request = [&](int tu) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const int col = 8 * g + 4 * k + (l >> 4);
+            const int col = 8 * gq + 4 * k + (l >> 4);
             hnext[k] = col < B ? H[((size_t)tu * B + col) * N + 16 * kb + (l & 15)] : 0.0f;
         }
     };
@@ -1815,7 +1820,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_we
     // input bytes of the eight columns: lane c < 8 loads column c's, a step ahead (a vector load on purpose: scalar loads
     // share the LDS wait counter and would serialise with every LDS access below)
     auto xfetch = [&](int tu) -> int {
-        const int col = 8 * g + (l & 7);
+        const int col = 8 * gq + (l & 7);
         const int x = col < B ? xi[(size_t)tu * B + col] : -2;
         return x == -1 ? 256 : x; // -1: empty input column -> bucket 256; -2: padding column, skipped
     };
@@ -1911,7 +1916,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_pr
     const __amdgpu_buffer_rsrc_t rQ = make_rsrc(DGx, bwds_ring_floats(N, B) * sizeof(float));
     auto qoff = [&](int tt, int hf) { // float offset of this lane's 16 bytes in slot(tt)
         const size_t slot = (size_t)((tt + ring_base) & (HX_RING - 1));
-        return ((((slot * NG + g) * 2 + hf) * NB + d) * NB + kb) * 64 + (size_t)u * 4;
+        return ((((slot * NGT_ + gq) * 2 + hf) * NB + d) * NB + kb) * 64 + (size_t)u * 4;
     };
     // FUSE: dWhy[:, units] += dy_t h_t^T (R/lstm.cc:226) between the products, while the wave would otherwise wait for the
     // next hand-off.  v_mfma_f32_4x4x1, one instruction = one column c, 64 output rows (lane l = row 64mg + l) and four units:
@@ -2052,7 +2057,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_el
     const int hf = w - 8;
     __builtin_amdgcn_s_setprio(3);
     const int cc = l >> 4, jj = l & 15;
-    const int ecol = 8 * g + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
+    const int ecol = 8 * gq + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
     const int j = 16 * kb + jj;
     float dcn = 0.0f; // dcnext, R/lstm.cc:217
     bool local_pub = false;
@@ -2061,7 +2066,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_el
     // this lane's piece of a slot: sources 4i + (l >> 4), unit l & 15, the four columns
     auto qbase = [&](int tt) {
         const size_t slot = (size_t)((tt + ring_base) & (HX_RING - 1));
-        return (int)((((((slot * NG + g) * 2 + hf) * NB + kb) * NB + (size_t)(l >> 4)) * 64 + (size_t)(l & 15) * 4) * sizeof(float));
+        return (int)((((((slot * NGT_ + gq) * 2 + hf) * NB + kb) * NB + (size_t)(l >> 4)) * 64 + (size_t)(l & 15) * 4) * sizeof(float));
     };
     // operands that do not depend on the chain are requested a step ahead
     float ig, og, fg, ug, cv, cp;
@@ -3076,16 +3081,21 @@ constexpr size_t DW_TABLE_BYTES = 257 * 64 * sizeof(float); // dynamic LDS of th
 //   second form (k_fwd_persistent2):   N = 128, 256, 512, 1024 otherwise (e.g. the evaluator's B = 1)
 //   first form (k_fwd_persistent):     every other multiple of 64
 static bool fwd_second_form(int N) { return N == 128 || N == 256 || N == 512 || N == 1024; }
+// Columns one launch of the fp32 two-half forms takes (N = 256, 512): as many 8-column groups as are co-resident at one
+// workgroup per CU.  A wider batch runs as several launches over column ranges (the streams are independent recurrences).
+int two_half_launch_cols(int N, int n_cus) { return 8 * (n_cus / (N / 16)); }
+bool two_half_wide(int N, int B, int n_cus) { return (N == 256 || N == 512) && B > two_half_launch_cols(N, n_cus) && n_cus >= N / 16; }
 bool fwd_uses_8col_form(int N, int B, int n_cus) {
-    return (N == 256 || N == 512 || N == 1024) && B > 8 && (N / 16) * ((B + 7) / 8) <= n_cus;
+    return (N == 256 || N == 512 || N == 1024) && B > 8 && ((N / 16) * ((B + 7) / 8) <= n_cus || two_half_wide(N, B, n_cus));
 }
 // 8-column groups in the backward recurrence when that still fits one workgroup per CU (more CUs pulling fewer bytes
 // each); on v_mfma_f32_4x4x1 for fp32 (N a multiple of 64)
-int bwd_group_cols(int N, int B, int n_cus) { return (N / 16) * ((B + 7) / 8) <= n_cus ? 8 : 16; }
+int bwd_group_cols(int N, int B, int n_cus) { return (N / 16) * ((B + 7) / 8) <= n_cus || two_half_wide(N, B, n_cus) ? 8 : 16; }
 bool bwd_uses_m4(int N, int cols, bool bf16) { return cols == 8 && !bf16 && N % 64 == 0 && N <= 1024; }
 // floats in one column group's partial gradient block [dW | dU | db | dWhy]
 size_t bwd_partial_floats(int N) { return (size_t)4 * N * 256 + (size_t)4 * N * N + (size_t)4 * N + (size_t)256 * N; }
 
+bool bwd_scatter_supported(int N, int B, int n_cus, bool fused);
 // All workgroups of a recurrence wait on each other, so its grid must be co-resident.  The occupancy API is asked about
 // exactly the instantiation that will be launched, with its dynamic LDS; it can over-report by one block per CU
 // (MI355X_MICROARCH.md, residency), so one is taken off wherever more than one is claimed.
@@ -3096,6 +3106,9 @@ static bool grid_fits(size_t grid, int per_cu, int n_cus) {
 }
 bool persistent_supported(int N, int B, int n_cus, bool fused) {
     if (N % 64 != 0 || N > 1024) return false;
+    if (two_half_wide(N, B, n_cus)) // several launches per direction: the two-half forms or nothing
+        return (N == 512 ? blocks_per_cu(k_fwd_persistent6<512, false>, FWD4_THREADS) : blocks_per_cu(k_fwd_persistent6<256, false>, FWD4_THREADS)) >= 1 &&
+               bwd_scatter_supported(N, B, n_cus, fused);
     int fb = 0, bb = 0;
     size_t fwd_grid = 0;
     if (fwd_uses_8col_form(N, B, n_cus)) {
@@ -3420,11 +3433,11 @@ void fwd_persistent4(const float4 *Ufwd4, const float *W, const float *bias, flo
 bool fwd_uses_two_half_form(int N, int B, int n_cus) { return (N == 512 || N == 256) && fwd_uses_8col_form(N, B, n_cus); }
 void fwd_persistent6(const float4 *Ufwd5, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
-                     int poll_cfg, hipStream_t st, unsigned long long *stamps) {
-    const int NGh = (B + 7) / 8;
+                     int poll_cfg, hipStream_t st, unsigned long long *stamps, int col0, int cols) {
+    const int NGh = ((cols > 0 ? cols : B) + 7) / 8; // groups of this launch: columns [col0, col0 + cols)
     static const bool no_pin = getenv("LSTM_HIP_NO_PIN") && atoi(getenv("LSTM_HIP_NO_PIN")); // A/B
     const bool pinned = NGh < 8 && !no_pin; // one group per XCD (see the kernel)
-    poll_cfg = (poll_cfg & 0xffff) | (pinned ? NGh << 16 : 0);
+    poll_cfg = (poll_cfg & 0xffff) | (pinned ? NGh << 16 : 0) | ((col0 / 8) << 20);
     const dim3 grid(N / 16, pinned ? 8 : NGh), block(FWD4_THREADS);
 #define F6_GO(...)                                                                                                            \
     hipLaunchKernelGGL((k_fwd_persistent6<__VA_ARGS__>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch, \
@@ -3590,7 +3603,8 @@ int bwds_ring_advance(int ring_base, int S) { return (ring_base - (S - 2)) & (HX
 // scatter form of the backward recurrence (k_bwd_scatter): the shapes of the two-half form
 bool bwd_scatter_supported(int N, int B, int n_cus, bool fused) {
     if ((N != 512 && N != 256) || bwd_group_cols(N, B, n_cus) != 8) return false;
-    const size_t grid = (size_t)(N / 16) * ((B + 7) / 8);
+    const int lg = two_half_launch_cols(N, n_cus) / 8, ng = (B + 7) / 8;
+    const size_t grid = (size_t)(N / 16) * (ng < lg ? ng : lg); // of one launch
     int per_cu = 0;
     if (N == 512)
         per_cu = fused ? blocks_per_cu(k_bwd_scatter<512, true>, BWDH_THREADS, bwdh_lds_bytes(true))
@@ -3602,9 +3616,10 @@ bool bwd_scatter_supported(int N, int B, int n_cus, bool fused) {
 }
 void bwd_scatter(const float4 *Ubwd6, float *DG, const float *Why, const float *dY, const float *G, const float *C, const float *H,
                  const int32_t *xi, float *gpart, float *Qx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N,
-                 int S, int B, int cfg, hipStream_t st, unsigned long long *stamps) {
+                 int S, int B, int cfg, hipStream_t st, unsigned long long *stamps, int col0, int cols) {
     // fewer than 8 groups: pinned launch, one group per XCD (see BWDH_COMMON); cfg bit 16 (spread mapping, tests) keeps the plain one
-    const int NGh = (B + 7) / 8;
+    const int NGh = ((cols > 0 ? cols : B) + 7) / 8; // groups of this launch: columns [col0, col0 + cols)
+    cfg = (cfg & 0xffff) | ((col0 / 8) << 20);
     static const bool no_pin = getenv("LSTM_HIP_NO_PIN") && atoi(getenv("LSTM_HIP_NO_PIN")); // A/B
     const bool pinned = NGh < 8 && !(cfg & 16) && !no_pin;
     if (pinned) cfg |= NGh << 16;

@@ -27,6 +27,8 @@ def _run(lstm_hip, text, N, S, B, windows, lr, chunk=1000, flags=0):
     (256, 50, 32, 3000),    # BASELINE configs[1]
     (512, 20, 60, 3000),    # ragged batch: the last column group has a padded half
     (1024, 12, 16, 1500),   # hidden size of configs[4]: one-recurrence forms, unfused products
+    (512, 11, 96, 1000),    # wider than one launch: two launches per direction (64 + 32 columns), one ring region per group
+    (128, 25, 1, 3000),     # BASELINE configs[0]: the single-CU recurrences
 ])
 def test_two_handles_same_seed_bit_identical(N, S, B, windows):
     import lstm_hip

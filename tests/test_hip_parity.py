@@ -33,6 +33,9 @@ CASES = [
     (64, 3, 9, ((1, 8),)),               # ... two timesteps, ragged batch
     (256, 6, 3, ()),                     # fewer streams than one 8-column group
     (512, 5, 8, ((2, 7),)),              # exactly one 8-column group
+    (64, 9, 1, ()),                      # one stream, hidden 64: the single-CU recurrences' other instantiation
+    (512, 5, 88, ((1, 70),)),            # wider than one launch of the two-half forms holds: columns 0-63, then 64-87
+    (256, 4, 136, ()),                   # ... at hidden 256: 128 + 8 columns (the second launch is one pinned group)
 ]
 
 
