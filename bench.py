@@ -264,21 +264,24 @@ def main():
     if rank == 0:
         # the library fuses DHy / dWhy into the backward recurrence when it runs on 8-column groups (one workgroup per CU on
         # the 256 CUs of an MI355X) and hidden <= 512
+        # (wider batches at hidden 256 / 512: the same kernels, several launches over column ranges; one stream at hidden
+        # <= 128: single-CU recurrences, unfused)
         fl = kernel_flops(N, S, B, fused=not (args.flags & (64 | 128)) and N <= 512 and N % 64 == 0 and
-                          (N // 16) * ((B + 7) // 8) <= 256)
+                          ((N // 16) * ((B + 7) // 8) <= 256 or N in (256, 512)) and not (B == 1 and N in (64, 128)))
         mf = {k: v for k, v in kstats.items() if k in fl}
         if mf:
             dom = max(mf, key=lambda k: mf[k][1])
             calls, ms = mf[dom]
             avg_s = ms / calls * 1e-3
-            ach = fl[dom] / avg_s / 1e12
+            lpw = max(1, round(calls / max(args.profile_windows, 1)))  # launches per window (column ranges of a wide batch)
+            ach = fl[dom] / lpw / avg_s / 1e12
             # bf16 recurrence mode: the two recurrences run on the bf16 pipe (dense peak 2500 TFLOP/s); the PMC traffic
             # file was collected for the fp32 kernels only
             bf16_kernel = bool(args.flags & 128)  # every MFMA kernel of the bf16 path runs on the bf16 pipe
             peak = 2500.0 if bf16_kernel else PEAK_FP32_MFMA_TFLOPS
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom, N, S, B, "bf16" if bf16_kernel else "f32"),
-                        "avg_launch_us": round(avg_s * 1e6, 2), "flop_per_launch": fl[dom],
+                        "avg_launch_us": round(avg_s * 1e6, 2), "flop_per_launch": fl[dom] / lpw, "launches_per_window": lpw,
                         "window_frac": round((24.0 * N * N + 6.0 * 256 * N) * (value / world) / 1e12 / peak, 4)}
 
     if rank == 0:
