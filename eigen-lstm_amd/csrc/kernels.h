@@ -69,6 +69,8 @@ void fwd_persistent6(const float4 *Ufwd5, const float *W, const float *bias, flo
 // columns one launch of the fp32 two-half forms takes; a wider batch (two_half_wide) runs as launches over column ranges
 // [col0, col0 + cols) -- cols = 0: the whole batch
 int two_half_launch_cols(int N, int n_cus);
+int two_half_group_cols(int N, int B, int n_cus);     // forward: 8, or 4 (one half per workgroup) where the batch then fits one launch
+int bwd_scatter_group_cols(int N, int B, int n_cus);  // backward: the same rule; the fused partial blocks are one per group
 bool two_half_wide(int N, int B, int n_cus);
 // two-half (scatter) form of the backward recurrence (N = 512 / 256, 8-column groups): every workgroup advances its eight
 // columns as two alternating 4-column recurrences, multiplies its OWN dg_t into partial sums for all N outputs and scatters

@@ -132,6 +132,7 @@ struct lstm_hip_ctx {
     int ring_base = 0;       // slot of step 0 in the next launch
     float *DGx = nullptr;    // backward recurrence: the same kind of ring for dg
     int ring_base_b = 0;
+    int gpart_cols = 8;      // columns per fused partial gradient block (4 where the scatter form runs one half per workgroup)
     size_t DGx_floats = 0;   // size of the backward hand-off ring
     int poll_cfg = 0;        // LSTM_HIP_FWD_POLL: bits 0-7 s_sleep between polls, 8-15 first delay of the non-gating waves
     bool packed = false;
@@ -473,7 +474,7 @@ int do_backward(lstm_hip_ctx *h) {
     if (defer_fold) {
         h->fold_pending = true;
     } else if (fused) { // accumulated per column group inside the recurrence: fold the groups in order
-        const int NGb = (B + h->bwd_cols - 1) / h->bwd_cols;
+        const int NGb = (B + h->gpart_cols - 1) / h->gpart_cols;
         const size_t psz = bwd_partial_floats(N);
         // b and Why are adjacent both in the flat block and in the partial blocks: one fold covers both.  With the early
         // all-reduce below the folds go to st2 with it, so the dU product on `st` does not wait for them.
@@ -582,7 +583,7 @@ int do_allreduce(lstm_hip_ctx *h) {
 int do_adagrad(lstm_hip_ctx *h, double lr) {
     if (h->fold_pending) {
         h->fold_pending = false;
-        const int NGb = (h->cfg.B + h->bwd_cols - 1) / h->bwd_cols;
+        const int NGb = (h->cfg.B + h->gpart_cols - 1) / h->gpart_cols;
         RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
                                h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, h->gpart, NGb, bwd_partial_floats(h->cfg.N),
                                h->pl.by, h->n_slabs_dU > 0 ? h->slabs_dU : nullptr, h->n_slabs_dU,
@@ -791,7 +792,10 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
         h->poll_cfg = getenv("LSTM_HIP_FWD_POLL") ? atoi(getenv("LSTM_HIP_FWD_POLL")) : (h->fwd_cols4 ? 0 : 1);
     }
     if (h->persistent && want_fused && h->bwd_cols == 8)
-        ALLOC(h->gpart, (size_t)((B + h->bwd_cols - 1) / h->bwd_cols) * bwd_partial_floats(cfg->N));
+    {
+        h->gpart_cols = h->bwd_halves ? bwd_scatter_group_cols((int)N, (int)B, prop.multiProcessorCount) : h->bwd_cols;
+        ALLOC(h->gpart, (size_t)((B + h->gpart_cols - 1) / h->gpart_cols) * bwd_partial_floats(cfg->N));
+    }
     h->probe_overlap = getenv("LSTM_HIP_PROBE_OVERLAP") ? atoi(getenv("LSTM_HIP_PROBE_OVERLAP")) : 0;
     HIP_TRY(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));

@@ -737,6 +737,9 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
     // workgroups of XCD g, the workgroups of the other XCDs leave at once
     const int pin_ng = (poll_cfg >> 16) & 15;
     const int g0 = (poll_cfg >> 20) & 255; // first column group of this launch (a wide batch runs as launches over column ranges)
+    // bit 28: ONE half per workgroup (4-column groups; half B's gating wave leaves): where the chip has room for twice the
+    // workgroups, a half's data never waits behind the other half's matrix phase (k_fwd_halves_bf16 has the measurements)
+    const int GC = (poll_cfg >> 28) & 1 ? 4 : 8;
     const int NB3 = gridDim.x, NG = pin_ng ? pin_ng : (int)gridDim.y;
     const int lin_ = blockIdx.x + NB3 * blockIdx.y;
     const int kb = pin_ng ? lin_ >> 3 : GROUP_REMAP ? lin_ / NG : (int)blockIdx.x;
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
         int colv[2];
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            const int c = 8 * (g + g0) + 4 * hf + li;
+            const int c = GC * (g + g0) + 4 * hf + li;
             colv[hf] = c < B ? c : B - 1;
         }
         // h_0 of both halves (plain window state in H); later fragments come from the ring, requested a half-step ahead
@@ -778,6 +781,7 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
         for (int t = 1; t < S; t++) {
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
+                if (hf == 1 && GC == 4) continue;
                 if (hf == 0) { FSTAMP(3, 8) }
                 float4 bv = bvq[hf];
                 if (t > 1 && !__all(hx_ready(bv))) {
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
                 // looked at after this half's barrier: its round trip runs under the matrix instructions below
                 const int nslot = (t - 1 + hf + ring_base) & (HX_RING - 1);
                 const int noff = (int)((((size_t)nslot * B + colv[hf ^ 1]) * N + Kw * w + 4 * lb) * sizeof(float));
-                const bool req = hf == 0 ? t > 1 : t + 1 < S;
+                const bool req = GC == 8 && (hf == 0 ? t > 1 : t + 1 < S);
                 // four independent accumulation chains, one per register of the loaded fragment
                 f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
 #define F6(ab)                                                              \
@@ -823,6 +827,10 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
 #undef F6
                 __builtin_amdgcn_sched_barrier(0);
                 if (req) bvq[hf ^ 1] = ld_lane ? ld_sc1(rHx, noff) : float4{0.f, 0.f, 0.f, 0.f}; // behind the last matrix instruction (ahead of them: 236-240 us)
+                if (GC == 4) { // one half only: its next fragment cannot have been published yet, the poll above fetches it
+                    const float sv = __uint_as_float(HX_SENT);
+                    bvq[0] = ld_lane ? float4{sv, sv, sv, sv} : float4{0.f, 0.f, 0.f, 0.f};
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (hf == 0) { FSTAMP(3, 10) } else { FSTAMP(3, 6) }
                 // lane (unit, gate j), register i = column i of the half: one row of the image per (wave, column)
@@ -840,9 +848,10 @@ __global__ __launch_bounds__(FWD4_THREADS) void k_fwd_persistent6(const float4 *
     } else {
         // ---------------- wave 8: gates of half A; wave 9: gates of half B; lane = column*16 + unit ----------------
         const int hf = w - 8;
+        if (hf == 1 && GC == 4) return;
         __builtin_amdgcn_s_setprio(3); // the gates are on the chain; the other half's product, issuing beside them, is not
         const int gc = l >> 4, gu = l & 15;
-        const int col = 8 * (g + g0) + 4 * hf + gc, colc = col < B ? col : B - 1;
+        const int col = GC * (g + g0) + 4 * hf + gc, colc = col < B ? col : B - 1;
         const int j = 16 * kb + gu;
         float bs[4], cprev, wx[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1646,7 +1655,8 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -
     const int pin_ng_ = (cfg >> 16) & 15;                                                                                       \
     /* cfg bits 20-27: first column group of this launch (a wide batch runs as launches over column ranges); gq = the group    */ \
     /* of the whole batch: columns, the partial gradient block and the ring region go by it                                   */ \
-    const int g0_ = (cfg >> 20) & 255, NGT_ = (B + 7) / 8;                                                                      \
+    /* cfg bit 28: ONE half per workgroup (4-column groups; half B's elementwise wave idles): see k_fwd_persistent6          */ \
+    const int g0_ = (cfg >> 20) & 255, GC_ = (cfg >> 28) & 1 ? 4 : 8, NRG_ = 2 * ((B + 7) / 8);                                 \
     const int NBK = gridDim.x, NG = pin_ng_ ? pin_ng_ : (int)gridDim.y;                                                         \
     const int lin_ = blockIdx.x + NBK * blockIdx.y;                                                                             \
     /* cfg bit 16 (tests): keep the dispatch-order mapping, which spreads every column group over all XCDs -- the placement  */ \
@@ -1655,6 +1665,7 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -
     const int kb = pin_ng_ ? lin_ >> 3 : remap_ ? lin_ / NG : (int)blockIdx.x;                                                  \
     const int g = pin_ng_ ? lin_ & 7 : remap_ ? lin_ % NG : (int)blockIdx.y;                                                    \
     const int gq = g + g0_;                                                                                                     \
+    const int rg0_ = GC_ * gq / 4; /* ring regions are counted in halves: region of (group, half) = its first column / 4 */   \
     const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DGx, (size_t)HX_RING * G4 * B * sizeof(float));                                \
     unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;                                                               \
     /* a wave that gives up: the abort word ends the launch everywhere, the LDS word releases this workgroup's other waves */   \
@@ -1715,7 +1726,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_ou
     int yofs[2];
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
-        const int c = 8 * gq + 4 * hf + li;
+        const int c = GC_ * gq + 4 * hf + li;
         yofs[hf] = (c < B ? c : B - 1) * 256 + 16 * lY + 4 * lz;
     }
     // (named registers, not arrays: see the note on scratch memory in the git history of this file)
@@ -1756,12 +1767,21 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_ou
     auto h_request = [&](int tu) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const int col = 8 * gq + 4 * k + (l >> 4);
+            const int col = GC_ * gq + 4 * k + (l >> 4);
             hnext[k] = col < B ? H[((size_t)tu * B + col) * N + 16 * kb + (l & 15)] : 0.0f;
         }
     };
+    const bool one_half = GC_ == 4; // half B's columns belong to another workgroup: nothing staged, nothing computed for them
+#define OL_DROP_B()                                                              \
+    do {                                                                         \
+        if (one_half) {                                                          \
+            b0 = b1 = b2 = b3 = float4{0.f, 0.f, 0.f, 0.f};                      \
+            hnext[1] = 0.0f;                                                     \
+        }                                                                        \
+    } while (0)
     OL_REQUEST(S - 1);
     if (FUSE) h_request(S - 1);
+    OL_DROP_B();
     for (int tu = S - 1; tu >= 1; tu--) {
         const int t = tu;
         hcur[0] = hnext[0], hcur[1] = hnext[1];
@@ -1769,7 +1789,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_ou
         // slot tu & 3 held the term of step tu+4: both elementwise waves must have read it
         if (tu + 4 <= S - 1) {
             const unsigned need = (unsigned)(S - (tu + 4));
-            if (!lds_wait(&s_stage[0], need) || !lds_wait(&s_stage[1], need)) {
+            if (!lds_wait(&s_stage[0], need) || (!one_half && !lds_wait(&s_stage[1], need))) {
                 give_up();
                 break;
             }
@@ -1797,14 +1817,16 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_ou
         }
         float *dst = dhyb + (tu & 3) * 128;
         OL_HALF(a0, a1, a2, a3, 0);
-        OL_HALF(b0, b1, b2, b3, 1);
+        if (!one_half) OL_HALF(b0, b1, b2, b3, 1);
         HSTAMP(11, 14)
         if (tu >= 2) OL_REQUEST(tu - 1); // in flight until this wave comes round again
         if (FUSE && tu >= 2) h_request(tu - 1);
+        OL_DROP_B();
         asm volatile("" ::: "memory");
         if (l == 0) __hip_atomic_store(s_ol, (unsigned)(S - tu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         HSTAMP(11, 15)
     }
+#undef OL_DROP_B
 #undef OL_HALF
 #undef Y_STEP
 #undef OL_REQUEST
@@ -1820,8 +1842,8 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_we
     // input bytes of the eight columns: lane c < 8 loads column c's, a step ahead (a vector load on purpose: scalar loads
     // share the LDS wait counter and would serialise with every LDS access below)
     auto xfetch = [&](int tu) -> int {
-        const int col = 8 * gq + (l & 7);
-        const int x = col < B ? xi[(size_t)tu * B + col] : -2;
+        const int col = GC_ * gq + (l & 7);
+        const int x = col < B && (l & 7) < GC_ ? xi[(size_t)tu * B + col] : -2;
         return x == -1 ? 256 : x; // -1: empty input column -> bucket 256; -2: padding column, skipped
     };
     int xnext = xfetch(S - 1);
@@ -1831,7 +1853,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_we
         bool ok = true;
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            if (!ok) break;
+            if (!ok || (hf == 1 && GC_ == 4)) break;
             if (!lds_wait(&s_stage[hf], (unsigned)(S - tu))) {
                 ok = false;
                 break;
@@ -1916,7 +1938,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_pr
     const __amdgpu_buffer_rsrc_t rQ = make_rsrc(DGx, bwds_ring_floats(N, B) * sizeof(float));
     auto qoff = [&](int tt, int hf) { // float offset of this lane's 16 bytes in slot(tt)
         const size_t slot = (size_t)((tt + ring_base) & (HX_RING - 1));
-        return ((((slot * NGT_ + gq) * 2 + hf) * NB + d) * NB + kb) * 64 + (size_t)u * 4;
+        return (((slot * NRG_ + rg0_ + hf) * NB + d) * NB + kb) * 64 + (size_t)u * 4;
     };
     // FUSE: dWhy[:, units] += dy_t h_t^T (R/lstm.cc:226) between the products, while the wave would otherwise wait for the
     // next hand-off.  v_mfma_f32_4x4x1, one instruction = one column c, 64 output rows (lane l = row 64mg + l) and four units:
@@ -1966,7 +1988,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_pr
     for (int t = S - 1; t >= 2 && live; t--) {
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            if (!live) break;
+            if (!live || (hf == 1 && GC_ == 4)) break;
             if (hf == 0) { SSTAMP(3, 8) }
             // E(t) of this half has written dg_t: steps S-1 .. t of the parity of t, (S-1-t)/2 + 1 of them.  (Spinning on the LDS
             // word without lds_wait's 64-cycle pauses: 290 -> 303 us -- eight waves hammering the LDS slow the elementwise waves.)
@@ -2057,7 +2079,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_el
     const int hf = w - 8;
     __builtin_amdgcn_s_setprio(3);
     const int cc = l >> 4, jj = l & 15;
-    const int ecol = 8 * gq + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
+    const int ecol = GC_ * gq + 4 * hf + cc, ecolc = ecol < B ? ecol : B - 1;
     const int j = 16 * kb + jj;
     float dcn = 0.0f; // dcnext, R/lstm.cc:217
     bool local_pub = false;
@@ -2066,7 +2088,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_el
     // this lane's piece of a slot: sources 4i + (l >> 4), unit l & 15, the four columns
     auto qbase = [&](int tt) {
         const size_t slot = (size_t)((tt + ring_base) & (HX_RING - 1));
-        return (int)((((((slot * NGT_ + gq) * 2 + hf) * NB + kb) * NB + (size_t)(l >> 4)) * 64 + (size_t)(l & 15) * 4) * sizeof(float));
+        return (int)(((((slot * NRG_ + rg0_ + hf) * NB + kb) * NB + (size_t)(l >> 4)) * 64 + (size_t)(l & 15) * 4) * sizeof(float));
     };
     // operands that do not depend on the chain are requested a step ahead
     float ig, og, fg, ug, cv, cp;
@@ -2080,7 +2102,8 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_el
     const bool alive = lds_wait(s_ol, 1u);
     if (alive) dhy = dhyb[((S - 1) & 3) * 128 + (4 * hf + cc) * 16 + jj];
     else give_up();
-    for (int t = S - 1; t >= 1 && alive; t--) {
+    const bool idle = hf == 1 && GC_ == 4; // one half per workgroup: wave 9 only takes part in the closing barriers (db = 0)
+    for (int t = S - 1; t >= 1 && alive && !idle; t--) {
         SSTAMP(8, 0)
         float dhn = 0.0f;
         if (t < S - 1) {
@@ -3084,6 +3107,13 @@ static bool fwd_second_form(int N) { return N == 128 || N == 256 || N == 512 || 
 // Columns one launch of the fp32 two-half forms takes (N = 256, 512): as many 8-column groups as are co-resident at one
 // workgroup per CU.  A wider batch runs as several launches over column ranges (the streams are independent recurrences).
 int two_half_launch_cols(int N, int n_cus) { return 8 * (n_cus / (N / 16)); }
+// 8 columns per workgroup (two alternating halves), or 4 (one half, twice the workgroups) where the whole batch then still
+// fits one launch -- the forward form only (the fused backward form's side waves are built around eight columns)
+int two_half_group_cols(int N, int B, int n_cus) {
+    static const int force = getenv("LSTM_HIP_FWD_GCOLS") ? atoi(getenv("LSTM_HIP_FWD_GCOLS")) : 0; // A/B: 4 or 8
+    if ((N != 256 && N != 512) || force == 8 || (B + 3) / 4 > n_cus / (N / 16)) return 8;
+    return 4;
+}
 bool two_half_wide(int N, int B, int n_cus) { return (N == 256 || N == 512) && B > two_half_launch_cols(N, n_cus) && n_cus >= N / 16; }
 bool fwd_uses_8col_form(int N, int B, int n_cus) {
     return (N == 256 || N == 512 || N == 1024) && B > 8 && ((N / 16) * ((B + 7) / 8) <= n_cus || two_half_wide(N, B, n_cus));
@@ -3434,10 +3464,11 @@ bool fwd_uses_two_half_form(int N, int B, int n_cus) { return (N == 512 || N == 
 void fwd_persistent6(const float4 *Ufwd5, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
                      int poll_cfg, hipStream_t st, unsigned long long *stamps, int col0, int cols) {
-    const int NGh = ((cols > 0 ? cols : B) + 7) / 8; // groups of this launch: columns [col0, col0 + cols)
+    const int GC = two_half_group_cols(N, B, 256);
+    const int NGh = ((cols > 0 ? cols : B) + GC - 1) / GC; // groups of this launch: columns [col0, col0 + cols)
     static const bool no_pin = getenv("LSTM_HIP_NO_PIN") && atoi(getenv("LSTM_HIP_NO_PIN")); // A/B
     const bool pinned = NGh < 8 && !no_pin; // one group per XCD (see the kernel)
-    poll_cfg = (poll_cfg & 0xffff) | (pinned ? NGh << 16 : 0) | ((col0 / 8) << 20);
+    poll_cfg = (poll_cfg & 0xffff) | (pinned ? NGh << 16 : 0) | ((col0 / GC) << 20) | (GC == 4 ? 1 << 28 : 0);
     const dim3 grid(N / 16, pinned ? 8 : NGh), block(FWD4_THREADS);
 #define F6_GO(...)                                                                                                            \
     hipLaunchKernelGGL((k_fwd_persistent6<__VA_ARGS__>), grid, block, 0, st, Ufwd5, W, bias, H, C, G, xi, Hx, cnt, abortp, epoch, \
@@ -3598,6 +3629,11 @@ size_t bwd_ring_floats(int N, int B) {
     return dg > q ? dg : q;
 }
 int bwd_ring_advance(int ring_base, int S) { return (ring_base - (S - 1)) & (HX_RING - 1); }
+// columns per group of the fp32 scatter form for this shape (4 = one half per workgroup): the fused partial gradient blocks
+// are one per group
+int bwd_scatter_group_cols(int N, int B, int n_cus) {
+    return two_half_group_cols(N, B, n_cus) == 4 && !(getenv("LSTM_HIP_BWD_GCOLS") && atoi(getenv("LSTM_HIP_BWD_GCOLS")) == 8) ? 4 : 8;
+}
 int bwds_ring_advance(int ring_base, int S) { return (ring_base - (S - 2)) & (HX_RING - 1); }
 
 // scatter form of the backward recurrence (k_bwd_scatter): the shapes of the two-half form
@@ -3618,8 +3654,9 @@ void bwd_scatter(const float4 *Ubwd6, float *DG, const float *Why, const float *
                  const int32_t *xi, float *gpart, float *Qx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N,
                  int S, int B, int cfg, hipStream_t st, unsigned long long *stamps, int col0, int cols) {
     // fewer than 8 groups: pinned launch, one group per XCD (see BWDH_COMMON); cfg bit 16 (spread mapping, tests) keeps the plain one
-    const int NGh = ((cols > 0 ? cols : B) + 7) / 8; // groups of this launch: columns [col0, col0 + cols)
-    cfg = (cfg & 0xffff) | ((col0 / 8) << 20);
+    const int GC = bwd_scatter_group_cols(N, B, 256);
+    const int NGh = ((cols > 0 ? cols : B) + GC - 1) / GC; // groups of this launch: columns [col0, col0 + cols)
+    cfg = (cfg & 0xffff) | ((col0 / GC) << 20) | (GC == 4 ? 1 << 28 : 0);
     static const bool no_pin = getenv("LSTM_HIP_NO_PIN") && atoi(getenv("LSTM_HIP_NO_PIN")); // A/B
     const bool pinned = NGh < 8 && !(cfg & 16) && !no_pin;
     if (pinned) cfg |= NGh << 16;

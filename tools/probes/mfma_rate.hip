@@ -94,7 +94,7 @@ template <int NCH, bool DIST> __global__ __launch_bounds__(768) void k_distinct(
     if (s == 12345.678f) *sink = s;
 }
 template <int KIND> void run(const char *name, unsigned long long *dout, float *dsink) {
-    for (int waves : {4, 8}) {
+    for (int waves : {4, 8, 12, 16}) {
         hipLaunchKernelGGL(k<KIND>, dim3(1), dim3(64 * waves), 0, 0, dout, dsink);
         unsigned long long h[16];
         hipMemcpy(h, dout, sizeof(h), hipMemcpyDeviceToHost);
