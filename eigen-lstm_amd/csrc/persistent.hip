@@ -3116,7 +3116,12 @@ int two_half_group_cols(int N, int B, int n_cus) {
 }
 bool two_half_wide(int N, int B, int n_cus) { return (N == 256 || N == 512) && B > two_half_launch_cols(N, n_cus) && n_cus >= N / 16; }
 bool fwd_uses_8col_form(int N, int B, int n_cus) {
-    return (N == 256 || N == 512 || N == 1024) && B > 8 && ((N / 16) * ((B + 7) / 8) <= n_cus || two_half_wide(N, B, n_cus));
+    // (N = 256, 512: any batch -- with one half per workgroup and a pinned launch a single stream is one group of 32 / 16
+    // workgroups on one XCD, 1.8 us a step where the second form's 64 workgroups over all XCDs took 3.75; N = 1024 has the
+    // 8-column one-recurrence form only, which wants more than one group)
+    static const bool narrow_off = getenv("LSTM_HIP_NARROW_TWO_HALF") && atoi(getenv("LSTM_HIP_NARROW_TWO_HALF")) == 0; // A/B
+    return (N == 256 || N == 512 || N == 1024) && (B > 8 || ((N == 256 || N == 512) && !narrow_off)) &&
+           ((N / 16) * ((B + 7) / 8) <= n_cus || two_half_wide(N, B, n_cus));
 }
 // 8-column groups in the backward recurrence when that still fits one workgroup per CU (more CUs pulling fewer bytes
 // each); on v_mfma_f32_4x4x1 for fp32 (N a multiple of 64)
