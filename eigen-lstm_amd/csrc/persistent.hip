@@ -14,10 +14,18 @@
 //             k_fwd_persistent4   N = 1024, 8-column groups: one recurrence per workgroup, same ring, one barrier
 //             k_fwd_persistent2   second form: 8 units x 16 columns on 16x16x4 tiles, counters   (small N, B <= 8, bf16 twin)
 //             k_fwd_persistent    first form: 4 units x 16 columns, counters                     (N = 64 multiples, bf16 twin)
+//             k_fwd_halves_bf16   bf16 path, N = 256 / 512 / 1024: the two-half form on 4x4x4 bf16 blocks (32 units per workgroup
+//                                 at N = 1024, so that a group fits one XCD)
+//             k_small_fwd         one stream, N <= 128: the whole recurrence on one CU, no hand-off between CUs
 //   backward  k_bwd_scatter       N = 512 / 256, 8-column groups: two alternating 4-column recurrences, partial sums scattered to
 //                                 the owners of the outputs; side waves for the output-layer term and the dW sums  (the headline shape)
+//             k_bwd_scatter_bf16  bf16 path, N = 256 / 512 / 1024: the scatter form, unfused, phase-tagged ring without reset stores
+//             k_small_bwd         one stream, N <= 128: one CU
 //             k_bwd_persistent    everything else: 16x16x4 tiles or 4x4x1 blocks, 4 / 8 / 16-column groups, fp32 or bf16,
 //                                 sharded counters, optional fused sums
+// Placement of the two-half / scatter forms: a launch takes as many column groups as are co-resident at one workgroup per CU;
+// fewer than 8 groups are pinned one to an XCD (the other XCDs' workgroups return at once); a narrow batch runs one half (4
+// columns) per workgroup on twice the workgroups; a batch wider than a launch runs as launches over column ranges.
 //
 // Hand-off, counter form (first / second forward forms, k_bwd_persistent; cdna_hip_programming.md Guideline 16): the
 // producing wave stores its slice of h_t with sc1 (write-through) 16-byte stores, drains them (s_waitcnt vmcnt(0)), then ONE
@@ -3106,6 +3114,12 @@ constexpr size_t DW_TABLE_BYTES = 257 * 64 * sizeof(float); // dynamic LDS of th
 static bool fwd_second_form(int N) { return N == 128 || N == 256 || N == 512 || N == 1024; }
 // Columns one launch of the fp32 two-half forms takes (N = 256, 512): as many 8-column groups as are co-resident at one
 // workgroup per CU.  A wider batch runs as several launches over column ranges (the streams are independent recurrences).
+// CU count of the current device (the launchers' shape rules must agree with the ones lstm_hip_create applied)
+static int current_device_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 256;
+    return cus;
+}
 int two_half_launch_cols(int N, int n_cus) { return 8 * (n_cus / (N / 16)); }
 // 8 columns per workgroup (two alternating halves), or 4 (one half, twice the workgroups) where the whole batch then still
 // fits one launch -- the forward form only (the fused backward form's side waves are built around eight columns)
@@ -3469,7 +3483,7 @@ bool fwd_uses_two_half_form(int N, int B, int n_cus) { return (N == 512 || N == 
 void fwd_persistent6(const float4 *Ufwd5, const float *W, const float *bias, float *H, float *C, float *G, const int32_t *xi,
                      float *Hx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N, int S, int B, bool fast,
                      int poll_cfg, hipStream_t st, unsigned long long *stamps, int col0, int cols) {
-    const int GC = two_half_group_cols(N, B, 256);
+    const int GC = two_half_group_cols(N, B, current_device_cus());
     const int NGh = ((cols > 0 ? cols : B) + GC - 1) / GC; // groups of this launch: columns [col0, col0 + cols)
     static const bool no_pin = getenv("LSTM_HIP_NO_PIN") && atoi(getenv("LSTM_HIP_NO_PIN")); // A/B
     const bool pinned = NGh < 8 && !no_pin; // one group per XCD (see the kernel)
@@ -3659,7 +3673,7 @@ void bwd_scatter(const float4 *Ubwd6, float *DG, const float *Why, const float *
                  const int32_t *xi, float *gpart, float *Qx, unsigned *cnt, unsigned *abortp, unsigned epoch, int ring_base, int N,
                  int S, int B, int cfg, hipStream_t st, unsigned long long *stamps, int col0, int cols) {
     // fewer than 8 groups: pinned launch, one group per XCD (see BWDH_COMMON); cfg bit 16 (spread mapping, tests) keeps the plain one
-    const int GC = bwd_scatter_group_cols(N, B, 256);
+    const int GC = bwd_scatter_group_cols(N, B, current_device_cus());
     const int NGh = ((cols > 0 ? cols : B) + GC - 1) / GC; // groups of this launch: columns [col0, col0 + cols)
     cfg = (cfg & 0xffff) | ((col0 / GC) << 20) | (GC == 4 ? 1 << 28 : 0);
     static const bool no_pin = getenv("LSTM_HIP_NO_PIN") && atoi(getenv("LSTM_HIP_NO_PIN")); // A/B

@@ -104,12 +104,13 @@ def test_window_matches_oracle(N, S, B, empty, oracle32):
     np.testing.assert_allclose(got["mem"], mref, rtol=1e-3, atol=1e-3 * float(mref.max()))
 
 
-@pytest.mark.parametrize("flag_name", ["NO_FUSED_GRADS", "STEP_KERNELS"])
-def test_alternative_engines_agree(flag_name, oracle32):
+# (256, 7, 12) and (512, 6, 40): the unfused sums beside the two-half forms -- one half per workgroup (pinned groups) and two
+@pytest.mark.parametrize("flag_name,N,S,B", [("NO_FUSED_GRADS", 128, 9, 24), ("STEP_KERNELS", 128, 9, 24),
+                                             ("NO_FUSED_GRADS", 256, 7, 12), ("NO_FUSED_GRADS", 512, 6, 40)])
+def test_alternative_engines_agree(flag_name, N, S, B, oracle32):
     """The alternative engines kept in the library (unfused dW/db/DHy/dWhy, per-step engine) compute the same window as
     the default path."""
     import lstm_hip
-    N, S, B = 128, 9, 24
     P, xi, ti, h0, c0 = gu.random_case(N, S, B, seed=31, empty=((1, 3),))
     fw = oracle32.forward(N, 256, S, B, P, xi, ti, h0, c0)
     dref = oracle32.backward(N, 256, S, B, P, xi, ti, fw)
