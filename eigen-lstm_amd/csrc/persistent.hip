@@ -463,6 +463,17 @@ __device__ __forceinline__ bool hx_ready(const float4 &v) {
            __float_as_uint(v.w) != HX_SENT;
 }
 __device__ __forceinline__ float hx_canon(float v) { return __float_as_uint(v) == HX_SENT ? __uint_as_float(0x7FC00000u) : v; }
+#ifndef BWDS_TAGGED
+#define BWDS_TAGGED 0
+#endif
+// phase-tagged variant of the ring (no reset stores; k_bwd_scatter_bf16 has the description): the parity of a slot's use count
+// in the last mantissa bit of every word
+__device__ __forceinline__ float tag_mark(float v, unsigned phase) { return __uint_as_float((__float_as_uint(v) & ~1u) | phase); }
+__device__ __forceinline__ float tag_value(float v) { return __uint_as_float(__float_as_uint(v) & ~1u); }
+__device__ __forceinline__ bool tag_ready(const float4 &v, unsigned phase) {
+    return ((__float_as_uint(v.x) & __float_as_uint(v.y) & __float_as_uint(v.z) & __float_as_uint(v.w) & 1u) == phase) &&
+           (((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) & 1u) == phase);
+}
 
 // stamp slots [workgroup 0 | gridDim.x/2][t][16]: wave 3 (MFMA) 8-12, wave 8 (gating) 0-7
 #define FSTAMP(wave, k)                                                                                        \
@@ -1665,6 +1676,9 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -
     /* of the whole batch: columns, the partial gradient block and the ring region go by it                                   */ \
     /* cfg bit 28: ONE half per workgroup (4-column groups; half B's elementwise wave idles): see k_fwd_persistent6          */ \
     const int g0_ = (cfg >> 20) & 255, GC_ = (cfg >> 28) & 1 ? 4 : 8, NRG_ = 2 * ((B + 7) / 8);                                 \
+    /* BWDS_TAGGED (compile time, experiment): the ring without reset stores, the parity of a slot's use count in the last   */ \
+    /* mantissa bit of every word (k_bwd_scatter_bf16); ring_base is then a publication number                               */ \
+    constexpr bool tagged_ = BWDS_TAGGED != 0;                                                                                  \
     const int NBK = gridDim.x, NG = pin_ng_ ? pin_ng_ : (int)gridDim.y;                                                         \
     const int lin_ = blockIdx.x + NBK * blockIdx.y;                                                                             \
     /* cfg bit 16 (tests): keep the dispatch-order mapping, which spreads every column group over all XCDs -- the placement  */ \
@@ -1945,7 +1959,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_pr
     const int d = 4 * w + (lb >> 2), u = 4 * (lb & 3) + lj; // this lane's output: unit u of destination workgroup d
     const __amdgpu_buffer_rsrc_t rQ = make_rsrc(DGx, bwds_ring_floats(N, B) * sizeof(float));
     auto qoff = [&](int tt, int hf) { // float offset of this lane's 16 bytes in slot(tt)
-        const size_t slot = (size_t)((tt + ring_base) & (HX_RING - 1));
+        const size_t slot = (size_t)((tagged_ ? ring_base + (S - 1 - tt) : tt + ring_base) & (HX_RING - 1));
         return (((slot * NRG_ + rg0_ + hf) * NB + d) * NB + kb) * 64 + (size_t)u * 4;
     };
     // FUSE: dWhy[:, units] += dy_t h_t^T (R/lstm.cc:226) between the products, while the wave would otherwise wait for the
@@ -2023,6 +2037,10 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_pr
                 q.y = hx_canon((c0[1] + c1[1]) + (c2[1] + c3[1]));
                 q.z = hx_canon((c0[2] + c1[2]) + (c2[2] + c3[2]));
                 q.w = hx_canon((c0[3] + c1[3]) + (c2[3] + c3[3]));
+                if (tagged_) {
+                    const unsigned ph = (unsigned)((ring_base + (S - 1 - t)) >> 2) & 1u;
+                    q = float4{tag_mark(q.x, ph), tag_mark(q.y, ph), tag_mark(q.z, ph), tag_mark(q.w, ph)};
+                }
                 const float4 sent = {__uint_as_float(HX_SENT), __uint_as_float(HX_SENT), __uint_as_float(HX_SENT),
                                      __uint_as_float(HX_SENT)};
                 // this wave's older stores (the last reset) are complete
@@ -2031,10 +2049,10 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_pr
                 if (d < NB) { // (N = 256: every lane of an active wave has a destination; kept for clarity)
                     if (XCD_LOCAL && local) {
                         *reinterpret_cast<float4 *>(DGx + e_pub) = q;
-                        *reinterpret_cast<float4 *>(DGx + e_rst) = sent;
+                        if (!tagged_) *reinterpret_cast<float4 *>(DGx + e_rst) = sent;
                     } else {
                         st_sc1(q, rQ, (int)(e_pub * sizeof(float)));
-                        st_sc1(sent, rQ, (int)(e_rst * sizeof(float)));
+                        if (!tagged_) st_sc1(sent, rQ, (int)(e_rst * sizeof(float)));
                     }
                 }
                 if (hf == 0) { SSTAMP(3, 11) } else { SSTAMP(3, 7) }
@@ -2095,7 +2113,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_el
     const __amdgpu_buffer_rsrc_t rQ = make_rsrc(DGx, bwds_ring_floats(N, B) * sizeof(float));
     // this lane's piece of a slot: sources 4i + (l >> 4), unit l & 15, the four columns
     auto qbase = [&](int tt) {
-        const size_t slot = (size_t)((tt + ring_base) & (HX_RING - 1));
+        const size_t slot = (size_t)((tagged_ ? ring_base + (S - 1 - tt) : tt + ring_base) & (HX_RING - 1));
         return (int)(((((slot * NRG_ + rg0_ + hf) * NB + kb) * NB + (size_t)(l >> 4)) * 64 + (size_t)(l & 15) * 4) * sizeof(float));
     };
     // operands that do not depend on the chain are requested a step ahead
@@ -2117,6 +2135,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_el
         if (t < S - 1) {
             // Q_{t+1}: the partial sums every workgroup of the group computed from its dg_{t+1} for this workgroup's units
             const int off = qbase(t + 1);
+            const unsigned ph = (unsigned)((ring_base + (S - 2 - t)) >> 2) & 1u; // (tagged ring) parity of this use of the slot
             float4 v[NLD];
             bool ok = false;
             for (int spins = 0; spins <= SPIN_LIMIT; spins++) {
@@ -2124,7 +2143,7 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_el
 #pragma unroll
                 for (int i = 0; i < NLD; i++) v[i] = ld_sc1(rQ, off + i * (4 * 64 * (int)sizeof(float)));
 #pragma unroll
-                for (int i = 0; i < NLD; i++) gd = gd && hx_ready(v[i]);
+                for (int i = 0; i < NLD; i++) gd = gd && (tagged_ ? tag_ready(v[i], ph) : hx_ready(v[i]));
                 if (__all(gd)) {
                     ok = true;
                     break;
@@ -2139,6 +2158,10 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_el
                 break;
             }
             SSTAMP(8, 1)
+            if (tagged_) { // the parity bit is cleared before the sum
+#pragma unroll
+                for (int i = 0; i < NLD; i++) v[i] = float4{tag_value(v[i].x), tag_value(v[i].y), tag_value(v[i].z), tag_value(v[i].w)};
+            }
             // sum over the sources: lane-local over sources 4i + q (ascending i), then over the four rows q of 16 lanes
             float4 sm = v[0];
 #pragma unroll
@@ -3653,7 +3676,10 @@ int bwd_ring_advance(int ring_base, int S) { return (ring_base - (S - 1)) & (HX_
 int bwd_scatter_group_cols(int N, int B, int n_cus) {
     return two_half_group_cols(N, B, n_cus) == 4 && !(getenv("LSTM_HIP_BWD_GCOLS") && atoi(getenv("LSTM_HIP_BWD_GCOLS")) == 8) ? 4 : 8;
 }
-int bwds_ring_advance(int ring_base, int S) { return (ring_base - (S - 2)) & (HX_RING - 1); }
+int bwds_ring_advance(int ring_base, int S) {
+    if (BWDS_TAGGED) return (ring_base + (S > 2 ? S - 2 : 0)) & 7; // publication number: slot = low two bits, parity = bit 2
+    return (ring_base - (S - 2)) & (HX_RING - 1);
+}
 
 // scatter form of the backward recurrence (k_bwd_scatter): the shapes of the two-half form
 bool bwd_scatter_supported(int N, int B, int n_cus, bool fused) {
