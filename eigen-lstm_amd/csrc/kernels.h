@@ -186,11 +186,21 @@ void dW_sums(const float *DG, int T, int G4, float *dW, float *db, void *scratch
 // gpart != null: the gradient is still in pieces -- `n_groups` partial blocks [dW | - | db | dWhy] (group_stride floats apart)
 // and, when slabs != null, `n_slabs` split-K slabs of dU; they are summed here in the order the separate folds use and the
 // sums are also stored to dP.  by_off: float offset of dby in the flat block (dby is final in dP).
+// the NEXT window's slide (slide_window's arguments), carried by an Adagrad launch in extra workgroups: inside the window loop
+// the slide of window i+1 needs nothing Adagrad of window i produces and touches nothing it reads
+struct SlideJob {
+    const uint8_t *text;
+    uint64_t len;
+    uint64_t *pos;
+    int32_t *Xr, *Tr, *headp, *xi, *ti;
+    float *H, *C;
+    int S, B, N, stride, carry_col;
+};
 void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
              hipStream_t st, float4 *Ubwd4 = nullptr, float4 *Ufwd4 = nullptr, const float *gpart = nullptr, int n_groups = 0,
              size_t group_stride = 0, size_t by_off = 0, const float *slabs = nullptr, int n_slabs = 0, size_t slab_stride = 0,
              int half_forms = 0, void *u6b = nullptr, int u6_uw = 0, unsigned short *why_b = nullptr,
-             unsigned short *whyT_b = nullptr, size_t why_off = 0);
+             unsigned short *whyT_b = nullptr, size_t why_off = 0, const SlideJob *slide = nullptr);
 
 // ---- window builder on the device (OV/lstm_eigen_opt/lstm.cc:190-213): x/target rings + flat copies,
 //      cursor advance, and the h/c carry (column 1 -> column 0).  Single workgroup.

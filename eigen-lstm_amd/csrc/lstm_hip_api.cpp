@@ -107,6 +107,8 @@ struct lstm_hip_ctx {
     bool bwd_scatter16 = false;                   // bf16 backward recurrence in its scatter form (k_bwd_scatter_bf16)
     void *Ufwd6b = nullptr, *Hxb = nullptr;       // two-half bf16 forward form: weights image, bf16 hand-off ring
     bool fwd_halves16 = false;
+    bool slide_in_adagrad = true;                 // LSTM_HIP_SLIDE_IN_ADAGRAD=0 (per handle): A/B
+    bool carry_slide = false, pre_slid = false;   // window loop: this Adagrad launch carries the next window's slide / it has been done
     bool small = false;                           // one stream, hidden <= 128: both recurrences on one CU (k_small_fwd / k_small_bwd)
     bool dgt_written = false;                     // the backward recurrence wrote the transposed bf16 image of dg itself
     bool packed6b = false;                        // Ubwd6b is current (written by the Adagrad launch)
@@ -581,23 +583,29 @@ int do_allreduce(lstm_hip_ctx *h) {
 }
 
 int do_adagrad(lstm_hip_ctx *h, double lr) {
+    const SlideJob job{h->text, h->text_len, h->pos, h->Xr, h->Tr, h->head, h->xi, h->ti, h->H, h->C,
+                       h->cfg.S, h->cfg.B, h->cfg.N, h->stride, h->carry_col};
+    const SlideJob *sj = h->carry_slide ? &job : nullptr;
     if (h->fold_pending) {
         h->fold_pending = false;
         const int NGb = (h->cfg.B + h->gpart_cols - 1) / h->gpart_cols;
         RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
                                h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, h->gpart, NGb, bwd_partial_floats(h->cfg.N),
                                h->pl.by, h->n_slabs_dU > 0 ? h->slabs_dU : nullptr, h->n_slabs_dU,
-                               (size_t)4 * h->cfg.N * h->cfg.N, h->half_forms()));
+                               (size_t)4 * h->cfg.N * h->cfg.N, h->half_forms(), nullptr, 0, nullptr, nullptr, 0, sj));
     } else if (h->bf16) // the fp32 fragment images are not used by the bf16 path (its own are repacked by pack_U_bf16)
     {   // ... except the scatter-form backward image, whose 8-byte elements are the four rows an Adagrad thread holds
         RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, nullptr, nullptr, h->st, nullptr, nullptr,
                                nullptr, 0, 0, 0, nullptr, 0, 0, 0, h->bwd_scatter16 ? h->Ubwd6b : nullptr,
-                               bwd_scatter_bf16_units(h->cfg.N), h->Why_b, h->WhyT_b, h->pl.Why));
+                               bwd_scatter_bf16_units(h->cfg.N), h->Why_b, h->WhyT_b, h->pl.Why, sj));
         h->packed6b = h->bwd_scatter16;
     }
     else
     RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
-                           h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, nullptr, 0, 0, 0, nullptr, 0, 0, h->half_forms()));
+                           h->Ubwd4 ? nullptr : h->Ubwd, h->st, h->Ubwd4, h->Ufwd4, nullptr, 0, 0, 0, nullptr, 0, 0, h->half_forms(), nullptr, 0,
+                           nullptr, nullptr, 0, sj));
+    if (sj) h->pre_slid = true;
+    h->carry_slide = false;
     h->packed = true; // the fp32 U images were refreshed by the same launch (the bf16 path has none)
     h->packed16 = false;
     h->why_packed = h->bf16; // (the bf16 path's Adagrad launch has just rewritten both bf16 copies of Why)
@@ -732,6 +740,7 @@ static int create_body(lstm_hip_ctx *h, const lstm_hip_config *cfg, const hipDev
     h->persistent = !(cfg->flags & LSTM_HIP_STEP_KERNELS) &&                          // the dW table beside the weights
                     persistent_supported(cfg->N, cfg->B, prop.multiProcessorCount, want_fused);
     h->n_cus = prop.multiProcessorCount;
+    h->slide_in_adagrad = !(getenv("LSTM_HIP_SLIDE_IN_ADAGRAD") && atoi(getenv("LSTM_HIP_SLIDE_IN_ADAGRAD")) == 0);
     h->small = h->persistent && small_ok;
     h->bwd_cols = bwd_group_cols(cfg->N, cfg->B, prop.multiProcessorCount);
     if (cfg->flags & LSTM_HIP_BF16_RECURRENCE) { // refusals: lstm_hip_create, before anything is allocated
@@ -855,6 +864,7 @@ int lstm_hip_get_params(lstm_hip_t *h, int which, float *host_block) {
 }
 
 int lstm_hip_set_state(lstm_hip_t *h, int32_t t, const float *h_t, const float *c_t) {
+    if (h) h->pre_slid = false; // (a window slid ahead by an interrupted loop is not the caller's window any more)
     CHECK(h);
     if (t < 0 || t >= h->cfg.S) return fail(LSTM_HIP_EINVAL, "set_state: t=%d outside [0,%d)", t, h->cfg.S);
     const size_t n = (size_t)h->cfg.N * h->cfg.B;
@@ -883,6 +893,7 @@ int lstm_hip_get_activations(lstm_hip_t *h, int32_t t, float *g_t, float *probs_
 }
 
 int lstm_hip_set_window(lstm_hip_t *h, const int32_t *xi, const int32_t *ti) {
+    if (h) h->pre_slid = false; // (a window slid ahead by an interrupted loop is not the caller's window any more)
     CHECK(h);
     if (!xi || !ti) return fail(LSTM_HIP_EINVAL, "set_window: null pointer");
     const size_t n = (size_t)h->cfg.S * h->cfg.B;
@@ -898,6 +909,7 @@ int lstm_hip_set_window(lstm_hip_t *h, const int32_t *xi, const int32_t *ti) {
     return 0;
 }
 int lstm_hip_set_inputs_dense(lstm_hip_t *h, const float *h0, const float *c0, const float *x, const float *target) {
+    if (h) h->pre_slid = false; // (a window slid ahead by an interrupted loop is not the caller's window any more)
     CHECK(h);
     if (!x || !target) return fail(LSTM_HIP_EINVAL, "set_inputs_dense: null x or target");
     const size_t cols = (size_t)h->cfg.S * h->cfg.B;
@@ -1007,6 +1019,7 @@ int lstm_hip_allreduce_grads(lstm_hip_t *h) {
 }
 
 int lstm_hip_set_text(lstm_hip_t *h, const uint8_t *text, size_t len) {
+    if (h) h->pre_slid = false; // (a window slid ahead by an interrupted loop is not the caller's window any more)
     CHECK(h);
     if (!text || len <= (size_t)h->cfg.S) return fail(LSTM_HIP_EINVAL, "set_text: need more than S=%d bytes (got %zu)", h->cfg.S, len);
     HIP_TRY(hipStreamSynchronize(h->st));
@@ -1018,6 +1031,7 @@ int lstm_hip_set_text(lstm_hip_t *h, const uint8_t *text, size_t len) {
     return 0;
 }
 int lstm_hip_set_cursors(lstm_hip_t *h, const uint64_t *pos) {
+    if (h) h->pre_slid = false; // (a window slid ahead by an interrupted loop is not the caller's window any more)
     CHECK(h);
     if (!pos) return fail(LSTM_HIP_EINVAL, "set_cursors: null pointer");
     if (!h->text) return fail(LSTM_HIP_ESTATE, "set_cursors before set_text");
@@ -1035,6 +1049,7 @@ int lstm_hip_get_cursors(lstm_hip_t *h, uint64_t *pos) {
     return 0;
 }
 int lstm_hip_set_stride(lstm_hip_t *h, int32_t stride, int32_t carry_col) {
+    if (h) h->pre_slid = false; // (a window slid ahead by an interrupted loop is not the caller's window any more)
     if (!h) return fail(LSTM_HIP_EINVAL, "null handle");
     if (stride < 1 || stride >= h->cfg.S || carry_col < 0 || carry_col >= h->cfg.S)
         return fail(LSTM_HIP_EINVAL, "set_stride: need 1 <= stride < S and 0 <= carry_col < S (got %d, %d)", stride, carry_col);
@@ -1088,13 +1103,17 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
             h->n_slabs_dU = 0;
             h->dby_done = false;
             h->fwd_done = false;
+            h->carry_slide = false;
             if (h->st2) (void)hipStreamSynchronize(h->st2); // side-stream work of the broken window (folds, early all-reduce)
             if (h->st) (void)hipStreamSynchronize(h->st);
         }
     } guard{h};
     for (int64_t i = 0; i < count; i++) {
-        RUN(K_SLIDE, slide_window(h->text, h->text_len, h->pos, h->Xr, h->Tr, h->head, h->xi, h->ti, h->H, h->C,
-                                  h->cfg.S, h->cfg.B, h->cfg.N, h->stride, h->carry_col, h->st));
+        // (from the second window on the slide has been done by the previous window's Adagrad launch, in extra workgroups)
+        if (!h->pre_slid)
+            RUN(K_SLIDE, slide_window(h->text, h->text_len, h->pos, h->Xr, h->Tr, h->head, h->xi, h->ti, h->H, h->C,
+                                      h->cfg.S, h->cfg.B, h->cfg.N, h->stride, h->carry_col, h->st));
+        h->pre_slid = false;
         int rc = 0;
         if ((rc = do_forward(h))) return rc;
         RUN(K_LOSS, loss_reduce(loss_src(h), loss_steps(h), h->cfg.B, h->global_B, h->d_losses + i, h->dby_part,
@@ -1102,6 +1121,11 @@ int lstm_hip_train_windows(lstm_hip_t *h, int64_t count, double learning_rate, d
         h->dby_done = true;
         if ((rc = do_backward(h))) return rc;
         if ((rc = do_allreduce(h))) return rc;
+        // not behind the last window (the handle is left on the window it trained on) and not in a profiling pass
+        // ... and only for windows of up to 2 048 columns: the slide's one window-building workgroup has 256 threads there
+        // instead of 1 024 and outlasts the Adagrad workgroups at the headline shape (6 400 columns: 0.660 -> 0.665 ms, while
+        // configs[1] gains 4 us, configs[0] 2, configs[4] 3)
+        h->carry_slide = i + 1 < count && !h->profiling && h->slide_in_adagrad && (int64_t)h->cfg.S * h->cfg.B <= 2048;
         if ((rc = do_adagrad(h, learning_rate))) return rc;
     }
     if (elapsed_ms) {
