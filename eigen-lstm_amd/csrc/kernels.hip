@@ -1010,7 +1010,8 @@ __device__ __forceinline__ float adagrad1(float p, float d, float &m, float lr) 
 // the split-K slabs of the dU product -- and is summed here, in the order gemm_fold / k_gemm_reduce use (bit-identical),
 // then also stored to dP.  Saves three reduction launches and a round trip of the sums (single-GPU loop only: an
 // all-reduce needs the summed block first).
-// (a device function: the window loop's Adagrad launch carries the NEXT window's slide in extra workgroups, k_adagrad)
+// (k_slide_window's body once more as a device function: the window loop's Adagrad launch carries the NEXT window's slide in
+// extra workgroups for short windows, k_adagrad<.., SLIDE>)
 struct SlideArgs {
     const uint8_t *text; // null: nothing to do
     uint64_t len;
@@ -1070,18 +1071,19 @@ struct GradFold {
     SlideArgs slide;                // the next window's slide, done by the workgroups past ada_blocks (text null: none)
     int ada_blocks;
 };
-template <bool FOLD>
+template <bool FOLD, bool SLIDE = false>
 __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *__restrict__ dP,
                                                  float *__restrict__ mem, size_t n4, float lr, size_t u_off4, int N,
                                                  float4 *__restrict__ Ufwd, float4 *__restrict__ Ubwd,
                                                  float4 *__restrict__ Ubwd4, float4 *__restrict__ Ufwd4, GradFold fold,
                                                  int half_forms) {
-    if ((int)blockIdx.x >= fold.ada_blocks) { // the next window's slide: touches nothing this launch reads or writes
+    if (SLIDE && (int)blockIdx.x >= fold.ada_blocks) { // the next window's slide: touches nothing this launch reads or writes
         slide_body(fold.slide, (int)blockIdx.x - fold.ada_blocks, (int)gridDim.x - fold.ada_blocks);
         return;
     }
+    const size_t stride_ = (size_t)(SLIDE ? fold.ada_blocks : (int)gridDim.x) * blockDim.x;
     const size_t u_n4 = (size_t)N * N; // float4 count of U
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)fold.ada_blocks * blockDim.x) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride_) {
         float4 p = reinterpret_cast<float4 *>(P)[i];
         float4 d;
         if (FOLD && i < fold.by_off4) {
@@ -1189,12 +1191,14 @@ void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, 
     }
     const GradFold fold{gpart, n_groups, group_stride, by_off / 4, slabs, n_slabs, slab_stride, reinterpret_cast<uint2 *>(u6b), u6_uw, why_b, whyT_b, why_off / 4, (size_t)256 * N / 4, sl, blocks};
     blocks += extra;
-    if (gpart != nullptr)
-        hipLaunchKernelGGL(k_adagrad<true>, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4,
-                           Ufwd4, fold, half_forms);
+    if (gpart != nullptr && extra)
+        hipLaunchKernelGGL((k_adagrad<true, true>), dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4, fold, half_forms);
+    else if (gpart != nullptr)
+        hipLaunchKernelGGL((k_adagrad<true, false>), dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4, fold, half_forms);
+    else if (extra)
+        hipLaunchKernelGGL((k_adagrad<false, true>), dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4, fold, half_forms);
     else
-        hipLaunchKernelGGL(k_adagrad<false>, dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4,
-                           Ufwd4, fold, half_forms);
+        hipLaunchKernelGGL((k_adagrad<false, false>), dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4, fold, half_forms);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1207,15 +1211,54 @@ void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, 
 //   flat xi/ti (what the kernels read) are rewritten from the rings
 //   h[0] <- h[1], c[0] <- c[1]                                        opt:205-206
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_slide_window(const SlideArgs a) { slide_body(a, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(1024) void k_slide_window(const uint8_t *__restrict__ text, uint64_t len,
+                                                       uint64_t *__restrict__ pos, int32_t *__restrict__ Xr,
+                                                       int32_t *__restrict__ Tr, int32_t *__restrict__ headp,
+                                                       int32_t *__restrict__ xi, int32_t *__restrict__ ti,
+                                                       float *__restrict__ H, float *__restrict__ C, int S, int B,
+                                                       int NB4, int stride, int carry_col) {
+    if (blockIdx.x > 0) { // carry: column 0 of the next window is column `carry_col` of this one (opt:205-206: 1)
+        const size_t src = (size_t)carry_col * NB4;
+        for (int i = (blockIdx.x - 1) * blockDim.x + threadIdx.x; i < NB4; i += (gridDim.x - 1) * blockDim.x) {
+            reinterpret_cast<float4 *>(H)[i] = reinterpret_cast<const float4 *>(H)[src + i];
+            reinterpret_cast<float4 *>(C)[i] = reinterpret_cast<const float4 *>(C)[src + i];
+        }
+        return;
+    }
+    int head = *headp;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        uint64_t p = pos[b];
+        int hd = head;
+        for (int k = 0; k < stride; k++) { // stride > 1: the segment variant advances several bytes per window
+            hd = (hd + 1) % S;
+            const int last = (hd + S - 1) % S, prev = (hd + S - 2) % S;
+            const int event = text[p];
+            p++;
+            if (p >= len) p = (uint64_t)S;
+            Tr[last * B + b] = event;
+            Xr[last * B + b] = Tr[prev * B + b];
+        }
+        pos[b] = p;
+    }
+    head = (head + stride) % S;
+    __syncthreads();
+    for (int i = threadIdx.x; i < S * B; i += blockDim.x) {
+        const int t = i / B, b = i - t * B;
+        const int row = (head + t) % S;
+        xi[i] = Xr[row * B + b];
+        ti[i] = Tr[row * B + b];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *headp = head;
+}
 void slide_window(const uint8_t *text, uint64_t len, uint64_t *pos, int32_t *Xr, int32_t *Tr, int32_t *headp,
                   int32_t *xi, int32_t *ti, float *H, float *C, int S, int B, int N, int stride, int carry_col,
                   hipStream_t st) {
     const int nb4 = N * B / 4;
     int copy_blocks = (nb4 + 1023) / 1024;
     if (copy_blocks > 32) copy_blocks = 32;
-    const SlideArgs a{text, len, pos, Xr, Tr, headp, xi, ti, H, C, S, B, nb4, stride, carry_col};
-    hipLaunchKernelGGL(k_slide_window, dim3(1 + copy_blocks), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_slide_window, dim3(1 + copy_blocks), dim3(1024), 0, st, text, len, pos, Xr, Tr, headp, xi, ti, H,
+                       C, S, B, nb4, stride, carry_col);
 }
 
 // ------------------------------------------------------------------------------------------------
