@@ -383,41 +383,47 @@ void gemm_fold(const float *slabs, int splits, int M, int Nn, float *C, int ldc,
 // along m.  K must be a multiple of 64 (the packed images are zero-padded); split-K writes slabs like k_gemm.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-constexpr int HBM_ = 128, HBN_ = 128, HBK_ = 64, HLD_ = 72; // tile and the padded LDS row (elements)
+constexpr int HBK_ = 64, HLD_ = 72; // k-tile and the padded LDS row (elements)
+// TM x TN tile: 128 x 128 where that still gives the chip enough workgroups, 64 x 64 (one 32 x 32 instruction tile per wave)
+// for the small products of a narrow batch -- configs[4]'s Y = Why * H is 256 x 1 584: 26 tiles of 128 x 128, 100 of 64 x 64
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm_bf16(int M, int Nn, int K, const unsigned short *__restrict__ A, int lda,
                                                    const unsigned short *__restrict__ Bm, int ldb, float *__restrict__ C,
                                                    int ldc, int kchunk, size_t slab_stride) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short hl[]; // As[2][128*72] | Bs[2][128*72]
-    unsigned short *As = hl, *Bs = hl + 2 * HBM_ * HLD_;
+    constexpr int MI = TM / 64, NI = TN / 64, PA = TM / 32, PB = TN / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned short hl[]; // As[2][TM*72] | Bs[2][TN*72]
+    unsigned short *As = hl, *Bs = hl + 2 * TM * HLD_;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1;
-    const int m0 = blockIdx.x * HBM_, n0 = blockIdx.y * HBN_;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
     const int kbeg = blockIdx.z * kchunk, kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
     C += (size_t)blockIdx.z * slab_stride;
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < MI; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < NI; b++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
-    const int srow = tid >> 3, sch = (tid & 7) * 8; // staging: 32 rows x 8 chunks of 8 elements per pass, 4 passes
-    uint4 ra[4], rb[4];
+    const int srow = tid >> 3, sch = (tid & 7) * 8; // staging: 32 rows x 8 chunks of 8 elements per pass
+    uint4 ra[PA], rb[PB];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
+        for (int p = 0; p < PA; p++) {
             const int row = p * 32 + srow;
             ra[p] = (m0 + row < M) ? *reinterpret_cast<const uint4 *>(A + (size_t)(m0 + row) * lda + k0 + sch) : uint4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int p = 0; p < PB; p++) {
+            const int row = p * 32 + srow;
             rb[p] = (n0 + row < Nn) ? *reinterpret_cast<const uint4 *>(Bm + (size_t)(n0 + row) * ldb + k0 + sch) : uint4{0, 0, 0, 0};
         }
     };
     auto lstore = [&](int stage) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int row = p * 32 + srow;
-            *reinterpret_cast<uint4 *>(As + (size_t)stage * HBM_ * HLD_ + row * HLD_ + sch) = ra[p];
-            *reinterpret_cast<uint4 *>(Bs + (size_t)stage * HBN_ * HLD_ + row * HLD_ + sch) = rb[p];
-        }
+        for (int p = 0; p < PA; p++) *reinterpret_cast<uint4 *>(As + (size_t)stage * TM * HLD_ + (p * 32 + srow) * HLD_ + sch) = ra[p];
+#pragma unroll
+        for (int p = 0; p < PB; p++) *reinterpret_cast<uint4 *>(Bs + (size_t)stage * TN * HLD_ + (p * 32 + srow) * HLD_ + sch) = rb[p];
     };
     const int ntiles = (kend - kbeg) / HBK_;
     if (ntiles <= 0) return;
@@ -427,20 +433,19 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(int M, int Nn, int K, const u
     for (int kt = 0; kt < ntiles; kt++) {
         const int cur = kt & 1;
         if (kt + 1 < ntiles) gload(kbeg + (kt + 1) * HBK_);
-        const unsigned short *Ac = As + (size_t)cur * HBM_ * HLD_ + (wm * 64 + (l & 31)) * HLD_ + 8 * (l >> 5);
-        const unsigned short *Bc = Bs + (size_t)cur * HBN_ * HLD_ + (wn * 64 + (l & 31)) * HLD_ + 8 * (l >> 5);
+        const unsigned short *Ac = As + (size_t)cur * TM * HLD_ + (wm * (TM / 2) + (l & 31)) * HLD_ + 8 * (l >> 5);
+        const unsigned short *Bc = Bs + (size_t)cur * TN * HLD_ + (wn * (TN / 2) + (l & 31)) * HLD_ + 8 * (l >> 5);
 #pragma unroll
         for (int ks = 0; ks < HBK_ / 16; ks++) {
-            bf16x8_t af[2], bf[2];
+            bf16x8_t af[MI], bf[NI];
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                af[i] = *reinterpret_cast<const bf16x8_t *>(Ac + i * 32 * HLD_ + ks * 16);
-                bf[i] = *reinterpret_cast<const bf16x8_t *>(Bc + i * 32 * HLD_ + ks * 16);
-            }
+            for (int i = 0; i < MI; i++) af[i] = *reinterpret_cast<const bf16x8_t *>(Ac + i * 32 * HLD_ + ks * 16);
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++)
+            for (int i = 0; i < NI; i++) bf[i] = *reinterpret_cast<const bf16x8_t *>(Bc + i * 32 * HLD_ + ks * 16);
 #pragma unroll
-                for (int ni = 0; ni < 2; ni++)
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
         }
         if (kt + 1 < ntiles) lstore(cur ^ 1); // the other stage: its readers finished before the previous barrier
@@ -448,16 +453,22 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(int M, int Nn, int K, const u
     }
     // D[row][col] of the swapped product = C[m = col][n = row]
 #pragma unroll
-    for (int mi = 0; mi < 2; mi++)
+    for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++) {
-            const int m = m0 + wm * 64 + mi * 32 + (l & 31);
+        for (int ni = 0; ni < NI; ni++) {
+            const int m = m0 + wm * (TM / 2) + mi * 32 + (l & 31);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int n = n0 + wn * 64 + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                const int n = n0 + wn * (TN / 2) + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
                 if (m < M && n < Nn) C[(size_t)n * ldc + m] = acc[mi][ni][r];
             }
         }
+}
+// tile of a product: 64 x 64 while 128 x 128 tiles (times the split-K factor) would leave most of the chip without one
+static int gemm_bf16_tile(int M, int Nn, int splits) {
+    static const int force = getenv("LSTM_HIP_BF16_GEMM_TILE") ? atoi(getenv("LSTM_HIP_BF16_GEMM_TILE")) : 0; // A/B: 64 or 128
+    if (force == 64 || force == 128) return force;
+    return ((M + 127) / 128) * ((Nn + 127) / 128) * splits < 128 ? 64 : 128;
 }
 // splits > 1: slabs of M*Nn floats (ld = M) + ordered fold, as gemm().  K: multiple of 64.
 void gemm_bf16(int M, int Nn, int K, const unsigned short *A, int lda, const unsigned short *B, int ldb, float *C, int ldc,
@@ -469,14 +480,20 @@ void gemm_bf16(int M, int Nn, int K, const unsigned short *A, int lda, const uns
     float *out = splits > 1 ? slabs : C;
     const int ldo = splits > 1 ? M : ldc;
     const size_t stride = splits > 1 ? (size_t)M * Nn : 0;
-    const size_t lds = sizeof(unsigned short) * 2 * (HBM_ + HBN_) * HLD_;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_gemm_bf16, dim3((M + HBM_ - 1) / HBM_, (Nn + HBN_ - 1) / HBN_, splits), dim3(256), lds, st, M, Nn, K, A,
-                       lda, B, ldb, out, ldo, kchunk, stride);
+    const int T = gemm_bf16_tile(M, Nn, splits);
+    const size_t lds = sizeof(unsigned short) * 2 * (T + T) * HLD_;
+    if (T == 64) {
+        hipLaunchKernelGGL((k_gemm_bf16<64, 64>), dim3((M + 63) / 64, (Nn + 63) / 64, splits), dim3(256), lds, st, M, Nn, K, A, lda, B, ldb,
+                           out, ldo, kchunk, stride);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_gemm_bf16<128, 128>), dim3((M + 127) / 128, (Nn + 127) / 128, splits), dim3(256), lds, st, M, Nn, K, A, lda, B,
+                           ldb, out, ldo, kchunk, stride);
+    }
     if (splits > 1) gemm_reduce_launch(slabs, splits, M, Nn, C, ldc, st);
 }
 int gemm_bf16_pick_splits(int M, int Nn, int K) {
-    const int tiles = ((M + HBM_ - 1) / HBM_) * ((Nn + HBN_ - 1) / HBN_);
+    const int tiles = ((M + 127) / 128) * ((Nn + 127) / 128);
     int splits = 1;
     while (tiles * splits < 256 && K / (splits * 2) >= 4 * HBK_) splits *= 2; // fill the CUs, keep >= 4 k-tiles per split
     return splits;
