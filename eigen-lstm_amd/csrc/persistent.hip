@@ -3139,8 +3139,11 @@ static bool fwd_second_form(int N) { return N == 128 || N == 256 || N == 512 || 
 // workgroup per CU.  A wider batch runs as several launches over column ranges (the streams are independent recurrences).
 // CU count of the current device (the launchers' shape rules must agree with the ones lstm_hip_create applied)
 static int current_device_cus() {
+    static int cached_dev = -1, cached_cus = 0; // (a process drives one device; re-queried if that ever changes)
     int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev == cached_dev) return cached_cus;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 256;
+    cached_dev = dev, cached_cus = cus;
     return cus;
 }
 int two_half_launch_cols(int N, int n_cus) { return 8 * (n_cus / (N / 16)); }
@@ -3674,7 +3677,8 @@ int bwd_ring_advance(int ring_base, int S) { return (ring_base - (S - 1)) & (HX_
 // columns per group of the fp32 scatter form for this shape (4 = one half per workgroup): the fused partial gradient blocks
 // are one per group
 int bwd_scatter_group_cols(int N, int B, int n_cus) {
-    return two_half_group_cols(N, B, n_cus) == 4 && !(getenv("LSTM_HIP_BWD_GCOLS") && atoi(getenv("LSTM_HIP_BWD_GCOLS")) == 8) ? 4 : 8;
+    static const bool force8 = getenv("LSTM_HIP_BWD_GCOLS") && atoi(getenv("LSTM_HIP_BWD_GCOLS")) == 8; // A/B
+    return two_half_group_cols(N, B, n_cus) == 4 && !force8 ? 4 : 8;
 }
 int bwds_ring_advance(int ring_base, int S) {
     if (BWDS_TAGGED) return (ring_base + (S > 2 ? S - 2 : 0)) & 7; // publication number: slot = low two bits, parity = bit 2
