@@ -18,6 +18,7 @@
 //   a k-fast operand as 4 consecutive k per lane (one 16-byte load per 32-row subtile v: rows r0 + 32*v + i).
 // Out-of-range rows are clamped to the last valid address (their products only reach outputs that are never stored);
 // the k tail (K % 8, k-slow operands only) is one predicated group.
+#include <cstdlib>
 #include "kernels.h"
 
 namespace lstmk {
@@ -338,7 +339,13 @@ int gemm_regs(bool akf, bool bkf, int M, int Nn, int K, const float *A, int lda,
     float *out = splits > 1 ? slabs : C;
     const int ldo = splits > 1 ? M : ldc;
     const size_t stride = splits > 1 ? (size_t)M * Nn : 0;
-    if (!akf && !bkf) launch_regs<false, false, 4, 2, 4, 2>(M, Nn, K, A, lda, B, ldb, out, ldo, splits, kchunk, stride, st);
+    // 64 x 64 tiles for the small products of a narrow batch, where 128 x 64 tiles (times the split-K factor) would leave most
+    // of the chip without one (LSTM_HIP_GEMM_SMALL_TILES=0: A/B)
+    static const bool small_ok = !(getenv("LSTM_HIP_GEMM_SMALL_TILES") && atoi(getenv("LSTM_HIP_GEMM_SMALL_TILES")) == 0);
+    const bool small = small_ok && ((M + 127) / 128) * ((Nn + 63) / 64) * splits < 128;
+    if (!akf && !bkf && small) launch_regs<false, false, 2, 2, 4, 2>(M, Nn, K, A, lda, B, ldb, out, ldo, splits, kchunk, stride, st);
+    else if (!akf && !bkf) launch_regs<false, false, 4, 2, 4, 2>(M, Nn, K, A, lda, B, ldb, out, ldo, splits, kchunk, stride, st);
+    else if (!akf && bkf && small) launch_regs<false, true, 2, 2, 4, 2>(M, Nn, K, A, lda, B, ldb, out, ldo, splits, kchunk, stride, st);
     else if (!akf && bkf) launch_regs<false, true, 4, 2, 4, 2>(M, Nn, K, A, lda, B, ldb, out, ldo, splits, kchunk, stride, st);
     else if (akf && bkf) launch_regs<true, true, 2, 2, 4, 2>(M, Nn, K, A, lda, B, ldb, out, ldo, splits, kchunk, stride, st);
     else return -1; // k fast x k slow: no product of the window has this form
