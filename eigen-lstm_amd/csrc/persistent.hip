@@ -1688,6 +1688,7 @@ constexpr int BWDH_SYNC = 16; // words at the head of the LDS block: abort, -, -
     const int g = pin_ng_ ? lin_ & 7 : remap_ ? lin_ % NG : (int)blockIdx.y;                                                    \
     const int gq = g + g0_;                                                                                                     \
     const int rg0_ = GC_ * gq / 4; /* ring regions are counted in halves: region of (group, half) = its first column / 4 */   \
+    (void)tagged_, (void)rg0_, (void)NRG_; /* (not every role uses every one of these) */                                       \
     const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DGx, (size_t)HX_RING * G4 * B * sizeof(float));                                \
     unsigned *xcc_tab = cnt + (size_t)g * CNT_SLOTS * CNT_STRIDE;                                                               \
     /* a wave that gives up: the abort word ends the launch everywhere, the LDS word releases this workgroup's other waves */   \
@@ -1875,7 +1876,8 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwdh_we
         bool ok = true;
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            if (!ok || (hf == 1 && GC_ == 4)) break;
+            if (hf == 1 && GC_ == 4) continue;
+            if (!ok) break;
             if (!lds_wait(&s_stage[hf], (unsigned)(S - tu))) {
                 ok = false;
                 break;
@@ -2010,7 +2012,8 @@ template <int N_, bool FUSE, bool STAMP> __device__ __forceinline__ void bwds_pr
     for (int t = S - 1; t >= 2 && live; t--) {
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            if (!live || (hf == 1 && GC_ == 4)) break;
+            if (hf == 1 && GC_ == 4) continue;
+            if (!live) break;
             if (hf == 0) { SSTAMP(3, 8) }
             // E(t) of this half has written dg_t: steps S-1 .. t of the parity of t, (S-1-t)/2 + 1 of them.  (Spinning on the LDS
             // word without lds_wait's 64-cycle pauses: 290 -> 303 us -- eight waves hammering the LDS slow the elementwise waves.)
