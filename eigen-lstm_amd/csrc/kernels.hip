@@ -1088,7 +1088,14 @@ struct GradFold {
     SlideArgs slide;                // the next window's slide, done by the workgroups past ada_blocks (text null: none)
     int ada_blocks;
 };
-template <bool FOLD, bool SLIDE = false>
+template <int CTRL> __device__ __forceinline__ float quad_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// QUAD (the two-half forms' images, Ufwd5 + Ubwd6): inside U the four lanes of a quad take four consecutive k of one group of
+// four rows (element (rows 4rg..4rg+3, k = 4*kb4 + lane & 3) instead of consecutive row groups of one k), so that after a 4 x 4
+// transpose across the quad BOTH images are written in 16-byte pieces: Ubwd6 wants four rows of a column, Ufwd5 four values of
+// k of a row.  (Loads and stores of P / dP / mem stay runs of 256 bytes per sixteen lanes.)
+template <bool FOLD, bool SLIDE = false, bool QUAD = false>
 __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *__restrict__ dP,
                                                  float *__restrict__ mem, size_t n4, float lr, size_t u_off4, int N,
                                                  float4 *__restrict__ Ufwd, float4 *__restrict__ Ubwd,
@@ -1100,7 +1107,15 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *_
     }
     const size_t stride_ = (size_t)(SLIDE ? fold.ada_blocks : (int)gridDim.x) * blockDim.x;
     const size_t u_n4 = (size_t)N * N; // float4 count of U
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride_) {
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride_) {
+        size_t i = i0;
+        int q_kb4 = 0;
+        if (QUAD && i0 >= u_off4 && i0 < u_off4 + u_n4) { // (quads are aligned: every range of the flat block is a multiple of 4 float4s)
+            const size_t e = i0 - u_off4;
+            const int rg = (int)((e >> 2) % N);
+            q_kb4 = (int)((e >> 2) / N);
+            i = u_off4 + (size_t)(4 * q_kb4 + (int)(e & 3)) * N + rg;
+        }
         float4 p = reinterpret_cast<float4 *>(P)[i];
         float4 d;
         if (FOLD && i < fold.by_off4) {
@@ -1167,7 +1182,31 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *_
                     u4[ubwd45_index(r + 3, k, N, half_forms)] = p.w;
                 }
             }
-            if (Ufwd4 != nullptr) {
+            if (QUAD) { // lane q of the quad: row r + q, k = 4*kb4 .. +3 after the transpose
+                const int ta = threadIdx.x & 3;
+                float t0 = p.x, t1 = p.y, t2 = p.z, t3 = p.w;
+                {
+                    const float lo = (ta & 1) ? t0 : t1, hi = (ta & 1) ? t2 : t3;
+                    const float rlo = quad_dpp<0xB1>(lo), rhi = quad_dpp<0xB1>(hi); // quad_perm [1,0,3,2]
+                    if (ta & 1) {
+                        t0 = rlo;
+                        t2 = rhi;
+                    } else {
+                        t1 = rlo;
+                        t3 = rhi;
+                    }
+                    const float s0 = (ta & 2) ? t0 : t2, s1 = (ta & 2) ? t1 : t3;
+                    const float r0 = quad_dpp<0x4E>(s0), r1 = quad_dpp<0x4E>(s1); // quad_perm [2,3,0,1]
+                    if (ta & 2) {
+                        t0 = r0;
+                        t1 = r1;
+                    } else {
+                        t2 = r0;
+                        t3 = r1;
+                    }
+                }
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Ufwd4) + ufwd5_index(r + ta, 4 * q_kb4, N)) = float4{t0, t1, t2, t3};
+            } else if (Ufwd4 != nullptr) {
                 float *f4 = reinterpret_cast<float *>(Ufwd4);
                 f4[ufwd45_index(r + 0, k, N, half_forms)] = p.x;
                 f4[ufwd45_index(r + 1, k, N, half_forms)] = p.y;
@@ -1208,14 +1247,20 @@ void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, 
     }
     const GradFold fold{gpart, n_groups, group_stride, by_off / 4, slabs, n_slabs, slab_stride, reinterpret_cast<uint2 *>(u6b), u6_uw, why_b, whyT_b, why_off / 4, (size_t)256 * N / 4, sl, blocks};
     blocks += extra;
-    if (gpart != nullptr && extra)
-        hipLaunchKernelGGL((k_adagrad<true, true>), dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4, fold, half_forms);
-    else if (gpart != nullptr)
-        hipLaunchKernelGGL((k_adagrad<true, false>), dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4, fold, half_forms);
-    else if (extra)
-        hipLaunchKernelGGL((k_adagrad<false, true>), dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4, fold, half_forms);
-    else
-        hipLaunchKernelGGL((k_adagrad<false, false>), dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4, fold, half_forms);
+    static const bool quad_off = getenv("LSTM_HIP_ADAGRAD_QUAD") && atoi(getenv("LSTM_HIP_ADAGRAD_QUAD")) == 0; // A/B
+    const bool quad = !quad_off && Ufwd4 != nullptr && Ubwd4 != nullptr && Ufwd == nullptr && Ubwd == nullptr && (half_forms & 1) && (half_forms & 4);
+#define ADA_GO(F, S_, Q) \
+    hipLaunchKernelGGL((k_adagrad<F, S_, Q>), dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4, fold, half_forms)
+    const bool f = gpart != nullptr, sl_ = extra != 0;
+    if (f && sl_ && quad) ADA_GO(true, true, true);
+    else if (f && sl_) ADA_GO(true, true, false);
+    else if (f && quad) ADA_GO(true, false, true);
+    else if (f) ADA_GO(true, false, false);
+    else if (sl_ && quad) ADA_GO(false, true, true);
+    else if (sl_) ADA_GO(false, true, false);
+    else if (quad) ADA_GO(false, false, true);
+    else ADA_GO(false, false, false);
+#undef ADA_GO
 }
 
 // ------------------------------------------------------------------------------------------------
