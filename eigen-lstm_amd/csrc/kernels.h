@@ -200,7 +200,9 @@ void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, 
              hipStream_t st, float4 *Ubwd4 = nullptr, float4 *Ufwd4 = nullptr, const float *gpart = nullptr, int n_groups = 0,
              size_t group_stride = 0, size_t by_off = 0, const float *slabs = nullptr, int n_slabs = 0, size_t slab_stride = 0,
              int half_forms = 0, void *u6b = nullptr, int u6_uw = 0, unsigned short *why_b = nullptr,
-             unsigned short *whyT_b = nullptr, size_t why_off = 0, const SlideJob *slide = nullptr);
+             unsigned short *whyT_b = nullptr, size_t why_off = 0, const SlideJob *slide = nullptr, void *uf6b = nullptr,
+             int uf6_uw = 0);
+int fwd_halves_bf16_units(int N);
 
 // ---- window builder on the device (OV/lstm_eigen_opt/lstm.cc:190-213): x/target rings + flat copies,
 //      cursor advance, and the h/c carry (column 1 -> column 0).  Single workgroup.

@@ -1083,6 +1083,8 @@ struct GradFold {
     size_t slab_stride; // floats
     uint2 *u6b;         // bf16 path: the scatter-form backward image of U (persistent.hip, k_pack_U6_bf16), refreshed here; or null
     int u6_uw;          // its units per workgroup
+    uint2 *uf6b;        // ... and the two-half forward image (persistent.hip, k_pack_Ufwd6_bf16; QUAD launches only); or null
+    int uf6_uw;
     unsigned short *why_b, *whyT_b; // bf16 path: Why as bf16 in place order [hidden][256] and transposed [256][hidden]; or null
     size_t why_off4, why_n4;        // float4 range of Why in the flat block
     SlideArgs slide;                // the next window's slide, done by the workgroups past ada_blocks (text null: none)
@@ -1166,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *_
             auto b16 = [](float v) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v); };
             fold.u6b[idx] = uint2{b16(p.x) | (b16(p.y) << 16), b16(p.z) | (b16(p.w) << 16)};
         }
-        if ((Ufwd != nullptr || Ufwd4 != nullptr) && i >= u_off4 && i < u_off4 + u_n4) {
+        if ((Ufwd != nullptr || Ufwd4 != nullptr || (QUAD && fold.uf6b != nullptr)) && i >= u_off4 && i < u_off4 + u_n4) {
             const size_t e = i - u_off4;        // float4 index inside U: rows 4*(e % N) .. +3 of column e / N
             const int r = 4 * (int)(e % N), k = (int)(e / N);
             // Ubwd[kb][r4][l] = U[16*r4 + 4*(l>>4) + 0..3][16*kb + (l&15)]
@@ -1205,7 +1207,17 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *_
                         t3 = r1;
                     }
                 }
-                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Ufwd4) + ufwd5_index(r + ta, 4 * q_kb4, N)) = float4{t0, t1, t2, t3};
+                if (Ufwd4 != nullptr)
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Ufwd4) + ufwd5_index(r + ta, 4 * q_kb4, N)) = float4{t0, t1, t2, t3};
+                if (fold.uf6b != nullptr) { // the same four values as one 8-byte element of Ufwd6b (index as in k_pack_Ufwd6_bf16)
+                    const int row = r + ta, k0 = 4 * q_kb4, UW = fold.uf6_uw;
+                    const int gate = row / N, hid = row % N, kb = hid / UW, sx = (hid % UW) >> 4, ll = 4 * (hid & 15) + gate;
+                    const int Kw = N / 8, NRK = Kw >= 64 ? Kw / 64 : 1, NAB = Kw >= 64 ? 16 : Kw / 4, NSET = UW / 16;
+                    const int w = k0 / Kw, kk = k0 % Kw, rr = kk / 64, ab = (kk % 64) >> 2;
+                    auto b16 = [](float v) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v); };
+                    fold.uf6b[(((((size_t)kb * 8 + w) * NRK + rr) * NSET + sx) * NAB + ab) * 64 + ll] =
+                        uint2{b16(t0) | (b16(t1) << 16), b16(t2) | (b16(t3) << 16)};
+                }
             } else if (Ufwd4 != nullptr) {
                 float *f4 = reinterpret_cast<float *>(Ufwd4);
                 f4[ufwd45_index(r + 0, k, N, half_forms)] = p.x;
@@ -1231,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_adagrad(float *__restrict__ P, float *_
 void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, int N, float4 *Ufwd, float4 *Ubwd,
              hipStream_t st, float4 *Ubwd4, float4 *Ufwd4, const float *gpart, int n_groups, size_t group_stride, size_t by_off,
              const float *slabs, int n_slabs, size_t slab_stride, int half_forms, void *u6b, int u6_uw,
-             unsigned short *why_b, unsigned short *whyT_b, size_t why_off, const SlideJob *slide) {
+             unsigned short *why_b, unsigned short *whyT_b, size_t why_off, const SlideJob *slide, void *uf6b, int uf6_uw) {
     const size_t n4 = n / 4; // the flat block is a multiple of 4 floats (M = 256, N % 16 == 0)
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -1245,10 +1257,12 @@ void adagrad(float *P, float *dP, float *mem, size_t n, float lr, size_t u_off, 
                        slide->S, slide->B, nb4, slide->stride, slide->carry_col};
         extra = 1 + copy_blocks;
     }
-    const GradFold fold{gpart, n_groups, group_stride, by_off / 4, slabs, n_slabs, slab_stride, reinterpret_cast<uint2 *>(u6b), u6_uw, why_b, whyT_b, why_off / 4, (size_t)256 * N / 4, sl, blocks};
+    const GradFold fold{gpart, n_groups, group_stride, by_off / 4, slabs, n_slabs, slab_stride, reinterpret_cast<uint2 *>(u6b), u6_uw, reinterpret_cast<uint2 *>(uf6b), uf6_uw, why_b, whyT_b, why_off / 4, (size_t)256 * N / 4, sl, blocks};
     blocks += extra;
     static const bool quad_off = getenv("LSTM_HIP_ADAGRAD_QUAD") && atoi(getenv("LSTM_HIP_ADAGRAD_QUAD")) == 0; // A/B
-    const bool quad = !quad_off && Ufwd4 != nullptr && Ubwd4 != nullptr && Ufwd == nullptr && Ubwd == nullptr && (half_forms & 1) && (half_forms & 4);
+    const bool quad = !quad_off && Ufwd == nullptr && Ubwd == nullptr &&
+                      ((Ufwd4 != nullptr && Ubwd4 != nullptr && (half_forms & 1) && (half_forms & 4)) || // fp32 two-half forms
+                       (Ufwd4 == nullptr && Ubwd4 == nullptr && uf6b != nullptr));                          // bf16 two-half forms
 #define ADA_GO(F, S_, Q) \
     hipLaunchKernelGGL((k_adagrad<F, S_, Q>), dim3(blocks), dim3(256), 0, st, P, dP, mem, n4, lr, u_off / 4, N, Ufwd, Ubwd, Ubwd4, Ufwd4, fold, half_forms)
     const bool f = gpart != nullptr, sl_ = extra != 0;

@@ -112,6 +112,7 @@ struct lstm_hip_ctx {
     bool small = false;                           // one stream, hidden <= 128: both recurrences on one CU (k_small_fwd / k_small_bwd)
     bool dgt_written = false;                     // the backward recurrence wrote the transposed bf16 image of dg itself
     bool packed6b = false;                        // Ubwd6b is current (written by the Adagrad launch)
+    bool packedf6b = false;                       // ... and Ufwd6b
     // bf16 operands of the four time-batched products, k contiguous (kernels.h, gemm_bf16): Why^T and Why; per window
     // h^T [N][SBpad], dy^T [256][Tpad], dg^T [4N][Tpad] and dy [T][256]
     unsigned short *WhyT_b = nullptr, *Why_b = nullptr, *Ht_b = nullptr, *dYt_b = nullptr, *DGt_b = nullptr, *dYb = nullptr;
@@ -282,7 +283,7 @@ int launch_fwd_recurrence(lstm_hip_ctx *h) {
             // (the one-recurrence forms' images only where one of them runs)
             RUN(K_PACK_U, (h->fwd_halves16 && h->bwd_scatter16 ? (void)0 : pack_U_bf16(h->P + h->pl.U, h->Ufwd16, h->Ubwd16, N, h->st),
                            h->bwd_scatter16 && !h->packed6b ? pack_U6_bf16(h->P + h->pl.U, h->Ubwd6b, N, h->st) : (void)0,
-                           h->fwd_halves16 ? pack_Ufwd6_bf16(h->P + h->pl.U, h->Ufwd6b, N, h->st) : (void)0));
+                           h->fwd_halves16 && !h->packedf6b ? pack_Ufwd6_bf16(h->P + h->pl.U, h->Ufwd6b, N, h->st) : (void)0));
             h->packed16 = true;
         }
         if (h->fwd_halves16) { // as many 8-column groups per launch as are co-resident; the streams are independent
@@ -597,8 +598,11 @@ int do_adagrad(lstm_hip_ctx *h, double lr) {
     {   // ... except the scatter-form backward image, whose 8-byte elements are the four rows an Adagrad thread holds
         RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, nullptr, nullptr, h->st, nullptr, nullptr,
                                nullptr, 0, 0, 0, nullptr, 0, 0, 0, h->bwd_scatter16 ? h->Ubwd6b : nullptr,
-                               bwd_scatter_bf16_units(h->cfg.N), h->Why_b, h->WhyT_b, h->pl.Why, sj));
+                               bwd_scatter_bf16_units(h->cfg.N), h->Why_b, h->WhyT_b, h->pl.Why, sj,
+                               h->fwd_halves16 ? h->Ufwd6b : nullptr, fwd_halves_bf16_units(h->cfg.N)));
         h->packed6b = h->bwd_scatter16;
+        static const bool quad_off = getenv("LSTM_HIP_ADAGRAD_QUAD") && atoi(getenv("LSTM_HIP_ADAGRAD_QUAD")) == 0; // (A/B switch of adagrad())
+        h->packedf6b = h->fwd_halves16 && !quad_off;
     }
     else
     RUN(K_ADAGRAD, adagrad(h->P, h->dP, h->mem, h->pl.total, (float)lr, h->pl.U, h->cfg.N, h->Ufwd4 ? nullptr : h->Ufwd,
@@ -851,7 +855,7 @@ int lstm_hip_set_params(lstm_hip_t *h, int which, const float *host_block) {
     if (!dst || !host_block) return fail(LSTM_HIP_EINVAL, "set_params: bad block id %d or null pointer", which);
     HIP_TRY(hipMemcpyAsync(dst, host_block, sizeof(float) * h->pl.total, hipMemcpyHostToDevice, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
-    if (which == 0) h->packed = h->packed16 = h->packed6b = h->why_packed = false;
+    if (which == 0) h->packed = h->packed16 = h->packed6b = h->packedf6b = h->why_packed = false;
     return 0;
 }
 int lstm_hip_get_params(lstm_hip_t *h, int which, float *host_block) {
